@@ -1,0 +1,262 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+QUERY_DTYPE = np.dtype([("valid", "<i4"), ("u", "<f4"), ("v", "<f4"), ("radius", "<f4"),
+                        ("min_level", "<i4"), ("max_level", "<i4"), ("ur", "<f4"),
+                        ("level_aux", "<i4"), ("angle", "<f4"), ("observed", "<i4")])
+assert QUERY_DTYPE.itemsize == 40
+
+
+class Frame(C.Structure):
+    _fields_ = [("n", C.c_int32), ("keys", C.c_void_p), ("desc", C.c_void_p),
+                ("u_right", C.c_void_p), ("min_x", C.c_float), ("min_y", C.c_float),
+                ("max_x", C.c_float), ("max_y", C.c_float), ("grid_inv_w", C.c_float),
+                ("grid_inv_h", C.c_float), ("n_levels", C.c_int32),
+                ("scale_factors", C.c_void_p)]
+
+
+class Pyramids(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("left", C.c_void_p), ("right", C.c_void_p),
+                ("step_left", C.c_void_p), ("step_right", C.c_void_p),
+                ("cols_right", C.c_void_p), ("scale_factors", C.c_void_p),
+                ("inv_scale_factors", C.c_void_p)]
+
+
+def build():
+    """Compile the oracle with gcc (idempotent)."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liborb_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_get_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.oracle_extract.restype = C.c_int
+        L.oracle_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_level_padded.restype = C.c_void_p
+        L.oracle_level_padded.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_level_blurred.restype = C.c_void_p
+        L.oracle_level_blurred.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_level_candidates.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 3
+        L.oracle_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.oracle_cvround.argtypes = [C.c_double]
+        L.oracle_fast_atan2.restype = C.c_float
+        L.oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.oracle_det_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.oracle_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_int]
+        L.oracle_gauss7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_distribute_octree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_int]
+        L.oracle_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_three_maxima.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 3
+        L.oracle_features_in_area.argtypes = [C.POINTER(Frame), C.c_float, C.c_float, C.c_float,
+                                              C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_search_for_initialization.argtypes = [C.POINTER(Frame), C.POINTER(Frame),
+                                                       C.c_void_p, C.c_void_p, C.c_int,
+                                                       C.c_float, C.c_int]
+        L.oracle_search_by_projection_frame.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p,
+                                                        C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_search_by_projection_points.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p,
+                                                         C.c_int, C.c_void_p, C.c_void_p, C.c_float]
+        L.oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                    C.c_void_p, C.c_int, C.POINTER(Pyramids),
+                                                    C.c_int, C.c_float, C.c_float, C.c_void_p,
+                                                    C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class OracleExtractor:
+    """Mirror of ORBextractor (include/ORBextractor.h:45-110) over the C oracle."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.h = self.L.oracle_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if not self.h:
+            raise ValueError("oracle_create failed")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def close(self):
+        if self.h:
+            self.L.oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tables(self):
+        n = self.nlevels
+        sf, isf, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        nf = np.zeros(n, np.int32)
+        um = np.zeros(16, np.int32)
+        self.L.oracle_get_tables(self.h, _p(sf), _p(isf), _p(s2), _p(is2), _p(nf), _p(um))
+        return dict(scale=sf, inv_scale=isf, sigma2=s2, inv_sigma2=is2, feat=nf, umax=um)
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        cap = self.nfeatures + 3 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = self.L.oracle_extract(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                  _p(kps), _p(desc), cap)
+        if n < 0:
+            raise RuntimeError("oracle capacity")
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        if self.L.oracle_level_size(self.h, level, C.byref(w), C.byref(h)) != 0:
+            raise IndexError(level)
+        return w.value, h.value
+
+    def level_padded(self, level):
+        w, h = self.level_size(level)
+        p = self.L.oracle_level_padded(self.h, level)
+        buf = (C.c_uint8 * ((w + 38) * (h + 38))).from_address(p)
+        return np.frombuffer(buf, np.uint8).reshape(h + 38, w + 38).copy()
+
+    def level_blurred(self, level):
+        w, h = self.level_size(level)
+        p = self.L.oracle_level_blurred(self.h, level)
+        if not p:
+            return None
+        buf = (C.c_uint8 * (w * h)).from_address(p)
+        return np.frombuffer(buf, np.uint8).reshape(h, w).copy()
+
+    def level_candidates(self, level):
+        px, py, pr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = self.L.oracle_level_candidates(self.h, level, C.byref(px), C.byref(py), C.byref(pr))
+        if n == 0:
+            z = np.zeros(0, np.float32)
+            return z, z, z
+
+        def arr(p):
+            return np.frombuffer((C.c_float * n).from_address(p.value), np.float32).copy()
+        return arr(px), arr(py), arr(pr)
+
+    def level_keypoints(self, level):
+        p = C.c_void_p()
+        n = self.L.oracle_level_keypoints(self.h, level, C.byref(p))
+        if n == 0:
+            return np.zeros(0, KP_DTYPE)
+        return np.frombuffer((C.c_uint8 * (n * 28)).from_address(p.value), KP_DTYPE).copy()
+
+
+def make_frame(keys, desc, u_right, bounds, scale_factors, keep):
+    """Build a Frame view; `keep` collects the arrays so they outlive the struct.
+    bounds = (min_x, min_y, max_x, max_y); the grid is 64x48 (include/Frame.h:37-38)."""
+    keys = np.ascontiguousarray(keys, KP_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    keep += [keys, desc, sf, ur]
+    f = Frame()
+    f.n = len(keys)
+    f.keys, f.desc, f.u_right = _p(keys), _p(desc), _p(ur)
+    f.min_x, f.min_y, f.max_x, f.max_y = [np.float32(b) for b in bounds]
+    # Frame.cc:101-102: static_cast<float>(FRAME_GRID_COLS)/static_cast<float>(mnMaxX-mnMinX)
+    f.grid_inv_w = np.float32(64.0) / (np.float32(bounds[2]) - np.float32(bounds[0]))
+    f.grid_inv_h = np.float32(48.0) / (np.float32(bounds[3]) - np.float32(bounds[1]))
+    f.n_levels = len(sf)
+    f.scale_factors = _p(sf)
+    return f
+
+
+def features_in_area(frame, x, y, r, min_level=-1, max_level=-1):
+    out = np.zeros(max(frame.n, 1), np.int32)
+    n = lib().oracle_features_in_area(C.byref(frame), x, y, r, min_level, max_level, _p(out), len(out))
+    return out[:n].copy()
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().oracle_descriptor_distance(_p(a), _p(b))
+
+
+def search_for_initialization(f1, f2, prev_matched, window_size=100, nnratio=0.9, check_ori=True):
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.zeros(max(f1.n, 1), np.int32)
+    n = lib().oracle_search_for_initialization(C.byref(f1), C.byref(f2), _p(pm), _p(m12),
+                                               window_size, nnratio, int(check_ori))
+    return n, m12[:f1.n].copy(), pm
+
+
+def search_by_projection_frame(cur, queries, qdesc, taken=None, check_ori=True):
+    q = np.ascontiguousarray(queries, QUERY_DTYPE)
+    qd = np.ascontiguousarray(qdesc, np.uint8)
+    tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+    out = np.zeros(max(cur.n, 1), np.int32)
+    n = lib().oracle_search_by_projection_frame(C.byref(cur), _p(q), _p(qd), len(q), _p(tk),
+                                                _p(out), int(check_ori))
+    return n, out[:cur.n].copy()
+
+
+def search_by_projection_points(f, queries, qdesc, taken=None, nnratio=0.8):
+    q = np.ascontiguousarray(queries, QUERY_DTYPE)
+    qd = np.ascontiguousarray(qdesc, np.uint8)
+    tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+    out = np.zeros(max(f.n, 1), np.int32)
+    n = lib().oracle_search_by_projection_points(C.byref(f), _p(q), _p(qd), len(q), _p(tk),
+                                                 _p(out), nnratio)
+    return n, out[:f.n].copy()
+
+
+def compute_stereo_matches(keys_l, desc_l, keys_r, desc_r, levels_l, levels_r, scale, inv_scale,
+                           mbf, mb):
+    """levels_l/levels_r: lists of 2-D uint8 arrays (level ROIs, any row stride)."""
+    nl = len(levels_l)
+    keys_l = np.ascontiguousarray(keys_l, KP_DTYPE)
+    keys_r = np.ascontiguousarray(keys_r, KP_DTYPE)
+    desc_l = np.ascontiguousarray(desc_l, np.uint8)
+    desc_r = np.ascontiguousarray(desc_r, np.uint8)
+    pl = (C.c_void_p * nl)(*[a.ctypes.data for a in levels_l])
+    pr = (C.c_void_p * nl)(*[a.ctypes.data for a in levels_r])
+    sl = np.array([a.strides[0] for a in levels_l], np.int32)
+    sr = np.array([a.strides[0] for a in levels_r], np.int32)
+    cr = np.array([a.shape[1] for a in levels_r], np.int32)
+    sf = np.ascontiguousarray(scale, np.float32)
+    isf = np.ascontiguousarray(inv_scale, np.float32)
+    P = Pyramids(nl, C.cast(pl, C.c_void_p), C.cast(pr, C.c_void_p), _p(sl), _p(sr), _p(cr),
+                 _p(sf), _p(isf))
+    ur = np.zeros(max(len(keys_l), 1), np.float32)
+    dp = np.zeros(max(len(keys_l), 1), np.float32)
+    n = lib().oracle_compute_stereo_matches(_p(keys_l), _p(desc_l), len(keys_l), _p(keys_r),
+                                            _p(desc_r), len(keys_r), C.byref(P),
+                                            levels_l[0].shape[0], mbf, mb, _p(ur), _p(dp))
+    return n, ur[:len(keys_l)].copy(), dp[:len(keys_l)].copy()

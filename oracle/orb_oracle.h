@@ -1,0 +1,161 @@
+/*
+ * orb_oracle.h -- CPU oracle for the ORB front-end + descriptor matching path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under orb_slam2_comment_amd/ (the product)
+ * may include, link or call this.  Allowed users: tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg.
+ *
+ * PARITY STATUS: "parity unpinned" at the OpenCV boundary.  The reference
+ * (ORB-SLAM2) ships no tests/golden vectors, and its hot path needs OpenCV,
+ * which is absent from this image, so the reference cannot be built here.
+ * This file is a plain-C restatement of
+ *   - src/ORBextractor.cc (ctor :410-470, IC_Angle :77-104,
+ *     computeOrbDescriptor :108-147, DivideNode :481-537, DistributeOctTree
+ *     :539-763, ComputeKeyPointsOctTree :765-853, operator() :1043-1105,
+ *     ComputePyramid :1107-1132),
+ *   - the published algorithms of the OpenCV primitives it calls (FAST-9/16 with
+ *     NMS and cornerScore, resize INTER_LINEAR 8U, copyMakeBorder REFLECT_101,
+ *     GaussianBlur 7x7 sigma 2 8U, fastAtan2, cvRound),
+ *   - src/ORBmatcher.cc (SearchByProjection :45-129 and :1328-1470,
+ *     SearchForInitialization :405-520, ComputeThreeMaxima :1601-1642,
+ *     DescriptorDistance :1647-1663),
+ *   - src/Frame.cc (AssignFeaturesToGrid/PosInGrid/GetFeaturesInArea :230-245,
+ *     :327-392, ComputeStereoMatches :466-640).
+ * Pinned by known answers derivable from the reference text:
+ * per-level quotas, umax, pyramid sizes, scale tables, keypoint sizes.
+ *
+ * Choices where the reference itself is not deterministic:
+ *   octree tie-break = later-created node first; no FMA contraction;
+ *   sin/cos = det_sincos (double polynomial rounded to float);
+ *   GaussianBlur = integer kernel {18,34,49,55,49,34,18}/256 both passes,
+ *   (sum + 32768) >> 16 with saturation (OpenCV <= 3.3 scalar arithmetic).
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_MAX_LEVELS 16
+
+/* same 28-byte layout as cv::KeyPoint */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} oracle_kp;
+
+typedef struct oracle_extractor oracle_extractor;
+
+oracle_extractor *oracle_create(int nfeatures, float scale_factor, int nlevels,
+                                int ini_th, int min_th);
+void oracle_destroy(oracle_extractor *e);
+
+/* constructor tables (ORBextractor.cc:410-470) */
+void oracle_get_tables(const oracle_extractor *e, float *scale, float *inv_scale,
+                       float *sigma2, float *inv_sigma2, int *feat_per_level,
+                       int *umax16);
+
+/* ORBextractor::operator() -- returns number of keypoints (<= cap) or -1 if
+ * cap is too small.  kps: cap entries, desc: cap*32 bytes. */
+int oracle_extract(oracle_extractor *e, const uint8_t *img, int rows, int cols,
+                   int stride, oracle_kp *kps, uint8_t *desc, int cap);
+
+/* intermediates of the LAST oracle_extract call (for stage-by-stage parity) */
+int oracle_level_size(const oracle_extractor *e, int level, int *w, int *h);
+/* padded plane (w+38)x(h+38), tightly packed */
+const uint8_t *oracle_level_padded(const oracle_extractor *e, int level);
+/* blurred level, w x h, tightly packed (NULL if the level had no keypoints) */
+const uint8_t *oracle_level_blurred(const oracle_extractor *e, int level);
+/* FAST candidates handed to DistributeOctTree, in reference order:
+ * x,y relative to (minBorderX,minBorderY), response = score */
+int oracle_level_candidates(const oracle_extractor *e, int level, const float **x,
+                            const float **y, const float **resp);
+/* per-level keypoints after DistributeOctTree + orientation, level coordinates */
+int oracle_level_keypoints(const oracle_extractor *e, int level, const oracle_kp **kps);
+
+/* stand-alone primitives (restated OpenCV arithmetic) */
+int oracle_cvround(double v);
+float oracle_fast_atan2(float y, float x);
+void oracle_det_sincos(float angle_rad, float *c, float *s);
+void oracle_resize_linear(const uint8_t *src, int sstep, int sw, int sh,
+                          uint8_t *dst, int dstep, int dw, int dh);
+void oracle_gauss7(const uint8_t *src, int sstep, int w, int h, uint8_t *dst, int dstep);
+/* cv::FAST(type 9_16) on a sub-image; out arrays sized w*h; returns count */
+int oracle_fast(const uint8_t *img, int step, int w, int h, int threshold,
+                int nonmax, int *ox, int *oy, int *oscore);
+int oracle_distribute_octree(const float *x, const float *y, const float *resp, int n,
+                             int minX, int maxX, int minY, int maxY, int N,
+                             int *out_idx, int out_cap);
+
+/* ---- matching ---------------------------------------------------------- */
+int oracle_descriptor_distance(const uint8_t *a, const uint8_t *b);
+void oracle_three_maxima(const int *hist_sizes, int L, int *ind1, int *ind2, int *ind3);
+
+/* flat view of the Frame fields the matchers read */
+typedef struct {
+    int32_t n;
+    const oracle_kp *keys;    /* mvKeysUn (== mvKeys when undistorted) */
+    const uint8_t *desc;      /* n x 32 */
+    const float *u_right;     /* mvuRight, may be NULL (treated as -1) */
+    float min_x, min_y, max_x, max_y;  /* mnMinX.. */
+    float grid_inv_w, grid_inv_h;      /* mfGridElement{Width,Height}Inv */
+    int32_t n_levels;
+    const float *scale_factors;
+} oracle_frame;
+
+/* Frame::GetFeaturesInArea; returns count, indices in reference order */
+int oracle_features_in_area(const oracle_frame *f, float x, float y, float r,
+                            int min_level, int max_level, int32_t *out, int cap);
+
+/* ORBmatcher::SearchForInitialization */
+int oracle_search_for_initialization(const oracle_frame *f1, const oracle_frame *f2,
+                                     float *prev_matched_xy /* n1 x 2, in/out */,
+                                     int32_t *matches12 /* n1 out */, int window_size,
+                                     float nnratio, int check_ori);
+
+/* one projected query of SearchByProjection: already-projected (u,v) etc. */
+typedef struct {
+    int32_t valid;       /* 0 -> skipped (no map point / outlier / bad / not in view) */
+    float u, v;          /* projection in the searched frame */
+    float radius;        /* search radius in pixels */
+    int32_t min_level, max_level; /* GetFeaturesInArea level window */
+    float ur;            /* projected right coordinate (stereo check) */
+    int32_t level_aux;   /* by-points: predicted level; by-frame: last octave */
+    float angle;         /* query keypoint angle (rotation histogram) */
+    int32_t observed;    /* pMP->Observations()>0 (blocks the slot it takes) */
+} oracle_query;
+
+/* ORBmatcher::SearchByProjection(Frame&,const Frame&,th,bMono) :1328-1470 after
+ * projection.  taken[n] in: slot already holds an observed map point; out_assign[n]:
+ * index of the query assigned to each current-frame keypoint or -1. */
+int oracle_search_by_projection_frame(const oracle_frame *cur, const oracle_query *q,
+                                      const uint8_t *qdesc, int nq, const uint8_t *taken,
+                                      int32_t *out_assign, int check_ori);
+
+/* ORBmatcher::SearchByProjection(Frame&,vector<MapPoint*>,th) :45-129 */
+int oracle_search_by_projection_points(const oracle_frame *f, const oracle_query *q,
+                                       const uint8_t *qdesc, int nq, const uint8_t *taken,
+                                       int32_t *out_assign, float nnratio);
+
+/* Frame::ComputeStereoMatches :466-640.  pyramids: arrays of per-level
+ * pointers to the level ROI (not the padded origin), steps and sizes. */
+typedef struct {
+    int32_t n_levels;
+    const uint8_t *const *left;
+    const uint8_t *const *right;
+    const int32_t *step_left, *step_right;
+    const int32_t *cols_right;
+    const float *scale_factors, *inv_scale_factors;
+} oracle_pyramids;
+
+int oracle_compute_stereo_matches(const oracle_kp *keys_l, const uint8_t *desc_l, int nl,
+                                  const oracle_kp *keys_r, const uint8_t *desc_r, int nr,
+                                  const oracle_pyramids *pyr, int n_rows, float mbf, float mb,
+                                  float *u_right, float *depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
