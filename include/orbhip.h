@@ -1,0 +1,188 @@
+/*
+ * orbhip.h -- C ABI of the MI355X-native ORB front-end and descriptor matching.
+ *
+ * Drop-in boundary for ORB-SLAM2's hot path (citations are file:line in the
+ * reference tree).  Every entry point is plain C: pointers + sizes, int status
+ * (0 = ok, < 0 = error), never throws.  Host-pointer entry points are
+ * synchronous; *_device entry points enqueue on the handle's HIP stream and
+ * take/return device pointers.
+ *
+ *   orbhip_extractor_*        replaces class ORBextractor
+ *                             (include/ORBextractor.h:45-110, src/ORBextractor.cc:410-1132)
+ *   orbhip_extract            replaces ORBextractor::operator()  (include/ORBextractor.h:59-61)
+ *   orbhip_pyramid_level*     replaces the public member mvImagePyramid (include/ORBextractor.h:85)
+ *   orbhip_matcher_*          replaces class ORBmatcher (include/ORBmatcher.h:37-103)
+ *   orbhip_descriptor_distance  ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1647-1663)
+ *   orbhip_search_for_initialization  ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520)
+ *   orbhip_search_by_projection_frame ORBmatcher::SearchByProjection(Frame&,const Frame&,th,bMono)
+ *                                     (src/ORBmatcher.cc:1328-1470)
+ *   orbhip_search_by_projection_points ORBmatcher::SearchByProjection(Frame&,vector<MapPoint*>&,th)
+ *                                     (src/ORBmatcher.cc:45-129)
+ *   orbhip_compute_stereo_matches     Frame::ComputeStereoMatches (src/Frame.cc:466-640)
+ */
+#ifndef ORBHIP_H
+#define ORBHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBHIP_OK 0
+#define ORBHIP_E_ARG (-1)       /* bad argument */
+#define ORBHIP_E_HIP (-2)       /* HIP runtime error (see orbhip_last_error) */
+#define ORBHIP_E_CAPACITY (-3)  /* caller buffer / internal capacity too small */
+#define ORBHIP_E_SIZE (-4)      /* unsupported image geometry */
+#define ORBHIP_E_NODEVICE (-5)  /* no usable gfx950 device */
+
+#define ORBHIP_MAX_LEVELS 16
+
+/* Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id). */
+typedef struct orbhip_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbhip_keypoint;
+
+typedef struct orbhip_extractor orbhip_extractor;
+typedef struct orbhip_matcher orbhip_matcher;
+
+const char *orbhip_last_error(void);      /* thread-local text of the last failure */
+int orbhip_device_count(int *count);
+
+/* ---- ORBextractor ------------------------------------------------------- */
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (src/ORBextractor.cc:410-470) on HIP device `device`. */
+int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                            int min_th_fast, int device, orbhip_extractor **out);
+void orbhip_extractor_destroy(orbhip_extractor *e);
+
+/* GetLevels/GetScaleFactor(s)/GetInverseScaleFactors/GetScaleSigmaSquares/
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:63-83); arrays of nlevels floats,
+ * any pointer may be NULL.  feat_per_level = mnFeaturesPerLevel. */
+int orbhip_extractor_levels(const orbhip_extractor *e);
+int orbhip_extractor_tables(const orbhip_extractor *e, float *scale, float *inv_scale,
+                            float *sigma2, float *inv_sigma2, int32_t *feat_per_level);
+
+/* Upper bound of keypoints one frame can return for images of rows x cols
+ * (per level: max(quota + 3, 4 * initial nodes), src/ORBextractor.cc:669-737). */
+int orbhip_extractor_capacity(orbhip_extractor *e, int rows, int cols, int *cap);
+
+/* 7-tap blur weights (default {18,34,49,55,49,34,18}: OpenCV<=3.3 integer kernel for
+ * GaussianBlur(7x7, sigma 2) on 8U; out = sat((sum_v sum_u w_v w_u p + 2^15) >> 16)). */
+int orbhip_extractor_set_blur_kernel(orbhip_extractor *e, const int32_t w[7]);
+
+/* ORBextractor::operator()(image, mask(ignored), keypoints, descriptors)
+ * (src/ORBextractor.cc:1043-1105).  image: rows x cols uint8, row stride `stride` bytes (host).
+ * kps[cap], desc[cap*32] host buffers; *n = number of keypoints (0 is success). */
+int orbhip_extract(orbhip_extractor *e, const uint8_t *image, int rows, int cols, int stride,
+                   orbhip_keypoint *kps, uint8_t *desc, int cap, int *n);
+
+/* Batch of `batch` same-size frames, host buffers.  Frame b starts at
+ * images + b*frame_stride; outputs of frame b at kps + b*cap, desc + b*cap*32, n[b]. */
+int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, int rows, int cols,
+                         int stride, size_t frame_stride, orbhip_keypoint *kps, uint8_t *desc,
+                         int cap, int32_t *n);
+
+/* Same with device pointers; asynchronous on the handle's stream. d_n: int32[batch].
+ * d_status: int32[batch] (0 ok, ORBHIP_E_CAPACITY if cap was too small), may be NULL. */
+int orbhip_extract_batch_device(orbhip_extractor *e, const void *d_images, int batch, int rows,
+                                int cols, int stride, size_t frame_stride, void *d_kps,
+                                void *d_desc, int cap, void *d_n, void *d_status);
+int orbhip_extractor_sync(orbhip_extractor *e);
+void *orbhip_extractor_stream(orbhip_extractor *e); /* hipStream_t */
+
+/* mvImagePyramid[level] of frame `frame` of the last extract call: size and device pointer of
+ * the level ROI (valid until the next extract on this handle); row stride in bytes.  The ROI is
+ * surrounded by the 19-px BORDER_REFLECT_101 frame the reference allocates
+ * (src/ORBextractor.cc:1113-1128), so d_roi[-19*stride-19] is addressable. */
+int orbhip_pyramid_level(orbhip_extractor *e, int frame, int level, int *rows, int *cols,
+                         int *stride, const void **d_roi);
+/* Copy a level to host.  with_border != 0 copies the (rows+38)x(cols+38) padded plane. */
+int orbhip_pyramid_level_download(orbhip_extractor *e, int frame, int level, int with_border,
+                                  uint8_t *dst, int dst_stride);
+/* Debug/parity taps of the last call (host copies). */
+int orbhip_blurred_level_download(orbhip_extractor *e, int frame, int level, uint8_t *dst,
+                                  int dst_stride);
+/* FAST candidates of a level in reference order: x,y (relative to minBorder), score. */
+int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *x, int32_t *y,
+                            int32_t *score, int cap, int *n);
+
+/* Per-stage device time of the last (batched) extract, microseconds, measured with HIP events
+ * on the handle's stream: [0] pyramid, [1] FAST+NMS cells, [2] octree, [3] blur,
+ * [4] orientation+descriptors, [5] total.  Enabled by orbhip_extractor_set_profiling(e, 1). */
+int orbhip_extractor_set_profiling(orbhip_extractor *e, int on);
+int orbhip_extractor_stage_times(orbhip_extractor *e, float us[6]);
+
+/* ---- ORBmatcher --------------------------------------------------------- */
+
+/* Flat view of the Frame fields the matchers read (include/Frame.h). Host pointers. */
+typedef struct orbhip_frame_view {
+    int32_t n;                       /* N */
+    const orbhip_keypoint *keys;     /* mvKeysUn */
+    const uint8_t *desc;             /* mDescriptors, n x 32 */
+    const float *u_right;            /* mvuRight or NULL (monocular: all -1) */
+    float min_x, min_y, max_x, max_y; /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+    float grid_inv_w, grid_inv_h;    /* mfGridElementWidthInv, mfGridElementHeightInv */
+    int32_t n_levels;
+    const float *scale_factors;      /* mvScaleFactors */
+} orbhip_frame_view;
+
+/* One already-projected query of SearchByProjection (the shim does the projection with the
+ * reference's own cv::Mat arithmetic, src/ORBmatcher.cc:1360-1390 / src/Frame.cc:269-325). */
+typedef struct orbhip_query {
+    int32_t valid;        /* 0: skipped (no map point, outlier, bad, not in view, behind camera) */
+    float u, v;           /* projection in the searched frame */
+    float radius;         /* window half-size in px (th * scale[level], src/ORBmatcher.cc:1381,:69) */
+    int32_t min_level, max_level; /* GetFeaturesInArea level window (max_level -1 = open) */
+    float ur;             /* projected right-image coordinate (stereo consistency check) */
+    int32_t level_aux;    /* informational */
+    float angle;          /* angle of the query keypoint (rotation histogram) */
+    int32_t observed;     /* pMP->Observations() > 0: once assigned it blocks that slot */
+} orbhip_query;
+
+int orbhip_matcher_create(int device, orbhip_matcher **out);
+void orbhip_matcher_destroy(orbhip_matcher *m);
+
+/* Batched DescriptorDistance: dist[i*nb + j] = popcount(a_i xor b_j) (host buffers). */
+int orbhip_descriptor_distance(orbhip_matcher *m, const uint8_t *a, int na, const uint8_t *b,
+                               int nb, int32_t *dist);
+
+/* ORBmatcher::SearchForInitialization(F1,F2,vbPrevMatched,vnMatches12,windowSize) with
+ * mfNNratio = nnratio, mbCheckOrientation = check_ori.  prev_matched_xy: n1 x 2 floats, in/out.
+ * matches12: n1 int32 out. */
+int orbhip_search_for_initialization(orbhip_matcher *m, const orbhip_frame_view *f1,
+                                     const orbhip_frame_view *f2, float *prev_matched_xy,
+                                     int32_t *matches12, int window_size, float nnratio,
+                                     int check_ori, int *nmatches);
+
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) after projection.
+ * q[nq], qdesc[nq*32] = pMP->GetDescriptor(); taken[n] (may be NULL): slot already holds an
+ * observed map point.  assign[n] out: query index now held by each current keypoint or -1. */
+int orbhip_search_by_projection_frame(orbhip_matcher *m, const orbhip_frame_view *cur,
+                                      const orbhip_query *q, const uint8_t *qdesc, int nq,
+                                      const uint8_t *taken, int32_t *assign, int check_ori,
+                                      int *nmatches);
+
+/* ORBmatcher::SearchByProjection(F, vpMapPoints, th) after Frame::isInFrustum. */
+int orbhip_search_by_projection_points(orbhip_matcher *m, const orbhip_frame_view *f,
+                                       const orbhip_query *q, const uint8_t *qdesc, int nq,
+                                       const uint8_t *taken, int32_t *assign, float nnratio,
+                                       int *nmatches);
+
+/* Frame::ComputeStereoMatches.  The image pyramids are the ones left in the two extractor
+ * handles by their last extract call (frame indices frame_l / frame_r of those batches), i.e.
+ * mpORBextractorLeft/Right->mvImagePyramid.  keys/desc: host buffers (mvKeys, mDescriptors,
+ * mvKeysRight, mDescriptorsRight).  mb is passed explicitly (the reference reads it before
+ * assignment, src/Frame.cc:496 vs :114).  u_right[nl], depth[nl] out (mvuRight, mvDepth). */
+int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int frame_l,
+                                  orbhip_extractor *right, int frame_r,
+                                  const orbhip_keypoint *keys_l, const uint8_t *desc_l, int nl,
+                                  const orbhip_keypoint *keys_r, const uint8_t *desc_r, int nr,
+                                  float mbf, float mb, float *u_right, float *depth, int *nmatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBHIP_H */

@@ -1,0 +1,102 @@
+"""ctypes loader for liborbhip.so (the C ABI declared in include/orbhip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C
+orb_slam2_comment_amd/csrc`.  There is no CPU fallback: if the shared object is
+missing or fails to load, importing a compute entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbhip.so")
+
+OK, E_ARG, E_HIP, E_CAPACITY, E_SIZE, E_NODEVICE = 0, -1, -2, -3, -4, -5
+MAX_LEVELS = 16
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+QUERY_DTYPE = np.dtype([("valid", "<i4"), ("u", "<f4"), ("v", "<f4"), ("radius", "<f4"),
+                        ("min_level", "<i4"), ("max_level", "<i4"), ("ur", "<f4"),
+                        ("level_aux", "<i4"), ("angle", "<f4"), ("observed", "<i4")])
+assert KP_DTYPE.itemsize == 28 and QUERY_DTYPE.itemsize == 40
+
+
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("keys", C.c_void_p), ("desc", C.c_void_p),
+                ("u_right", C.c_void_p), ("min_x", C.c_float), ("min_y", C.c_float),
+                ("max_x", C.c_float), ("max_y", C.c_float), ("grid_inv_w", C.c_float),
+                ("grid_inv_h", C.c_float), ("n_levels", C.c_int32),
+                ("scale_factors", C.c_void_p)]
+
+
+# every symbol include/orbhip.h declares: (name, restype, argtypes)
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_pi = C.POINTER(C.c_int)
+SYMBOLS = [
+    ("orbhip_last_error", C.c_char_p, []),
+    ("orbhip_device_count", _i, [_pi]),
+    ("orbhip_extractor_create", _i, [_i, _f, _i, _i, _i, _i, C.POINTER(_vp)]),
+    ("orbhip_extractor_destroy", None, [_vp]),
+    ("orbhip_extractor_levels", _i, [_vp]),
+    ("orbhip_extractor_tables", _i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    ("orbhip_extractor_capacity", _i, [_vp, _i, _i, _pi]),
+    ("orbhip_extractor_set_blur_kernel", _i, [_vp, _vp]),
+    ("orbhip_extract", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _pi]),
+    ("orbhip_extract_batch", _i, [_vp, _vp, _i, _i, _i, _i, _sz, _vp, _vp, _i, _vp]),
+    ("orbhip_extract_batch_device", _i, [_vp, _vp, _i, _i, _i, _i, _sz, _vp, _vp, _i, _vp, _vp]),
+    ("orbhip_extractor_sync", _i, [_vp]),
+    ("orbhip_extractor_stream", _vp, [_vp]),
+    ("orbhip_pyramid_level", _i, [_vp, _i, _i, _pi, _pi, _pi, C.POINTER(_vp)]),
+    ("orbhip_pyramid_level_download", _i, [_vp, _i, _i, _i, _vp, _i]),
+    ("orbhip_blurred_level_download", _i, [_vp, _i, _i, _vp, _i]),
+    ("orbhip_level_candidates", _i, [_vp, _i, _i, _vp, _vp, _vp, _i, _pi]),
+    ("orbhip_extractor_set_profiling", _i, [_vp, _i]),
+    ("orbhip_extractor_stage_times", _i, [_vp, _vp]),
+    ("orbhip_matcher_create", _i, [_i, C.POINTER(_vp)]),
+    ("orbhip_matcher_destroy", None, [_vp]),
+    ("orbhip_descriptor_distance", _i, [_vp, _vp, _i, _vp, _i, _vp]),
+    ("orbhip_search_for_initialization", _i, [_vp, C.POINTER(FrameView), C.POINTER(FrameView), _vp,
+                                              _vp, _i, _f, _i, _pi]),
+    ("orbhip_search_by_projection_frame", _i, [_vp, C.POINTER(FrameView), _vp, _vp, _i, _vp, _vp,
+                                               _i, _pi]),
+    ("orbhip_search_by_projection_points", _i, [_vp, C.POINTER(FrameView), _vp, _vp, _i, _vp, _vp,
+                                                _f, _pi]),
+    ("orbhip_compute_stereo_matches", _i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f,
+                                           _f, _vp, _vp, _pi]),
+]
+
+_LIB = None
+
+
+class OrbHipError(RuntimeError):
+    def __init__(self, code, where):
+        msg = lib().orbhip_last_error()
+        super().__init__("%s failed with status %d: %s" % (where, code, (msg or b"").decode()))
+        self.code = code
+
+
+def lib():
+    """Load liborbhip.so and bind every declared symbol.  Raises if it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                              % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(code, where):
+    if code != OK:
+        raise OrbHipError(code, where)
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None

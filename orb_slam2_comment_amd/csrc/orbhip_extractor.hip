@@ -1,0 +1,1324 @@
+// MI355X (gfx950) ORB extractor: pyramid, per-cell FAST-9/16 + NMS, octree
+// distribution, IC-angle, 7x7 blur, steered rBRIEF -- behind the C ABI of
+// include/orbhip.h.  Replaces ORBextractor (src/ORBextractor.cc:410-1132).
+//
+// Batch-first design: every kernel takes a frame index in blockIdx.y, so one
+// launch covers a whole batch of frames; a frame's pyramid (8 padded uchar
+// planes) stays resident in HBM between the stages.  Integer/bitwise path:
+// no MFMA.  All float arithmetic that feeds a rounding decision is written
+// with explicit, un-contracted operations.
+#include "orbhip_common.h"
+#include "rbrief_pattern.h"
+
+#include <cfloat>
+#include <cmath>
+#include <mutex>
+#include <new>
+#include <vector>
+
+namespace orbhip {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_reduce_add(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Exclusive scan of one int per thread over a 256-thread block.  `sh` = 8 ints of LDS.
+// Returns the exclusive prefix; *total receives the block sum.  Ends with a barrier.
+__device__ __forceinline__ int block_excl_scan256(int v, int *sh, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    __syncthreads();  // protect sh reuse across consecutive calls
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        int s = sh[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// cv::fastAtan2 (degrees in [0,360)); same float operation sequence as the oracle.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, (float)DBL_EPSILON));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, (float)DBL_EPSILON));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// Deterministic stand-in for (float)cos / (float)sin of ORBextractor.cc:113: IEEE double,
+// separate multiplies and adds (no FMA), one final rounding to float.  Bit-identical to
+// oracle_det_sincos by construction.
+__device__ __forceinline__ void det_sincos(float angle_rad, float *c, float *s)
+{
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_hi = 1.57079632673412561417e+00;
+    const double pio2_lo = 6.07710050650619224932e-11;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double x = (double)angle_rad;
+    double kd = floor(__dadd_rn(__dmul_rn(x, two_over_pi), 0.5));
+    int k = (int)kd;
+    double r = __dsub_rn(__dsub_rn(x, __dmul_rn(kd, pio2_hi)), __dmul_rn(kd, pio2_lo));
+    double z = __dmul_rn(r, r);
+    double ps = __dadd_rn(S1, __dmul_rn(z, __dadd_rn(S2, __dmul_rn(z, __dadd_rn(S3, __dmul_rn(z, __dadd_rn(S4, __dmul_rn(z, __dadd_rn(S5, __dmul_rn(z, S6))))))))));
+    double sn = __dadd_rn(r, __dmul_rn(__dmul_rn(r, z), ps));
+    double pc = __dadd_rn(C1, __dmul_rn(z, __dadd_rn(C2, __dmul_rn(z, __dadd_rn(C3, __dmul_rn(z, __dadd_rn(C4, __dmul_rn(z, __dadd_rn(C5, __dmul_rn(z, C6))))))))));
+    double cs = __dadd_rn(__dsub_rn(1.0, __dmul_rn(0.5, z)), __dmul_rn(__dmul_rn(z, z), pc));
+    double so, co;
+    switch (k & 3) {
+    case 0: so = sn; co = cs; break;
+    case 1: so = cs; co = -sn; break;
+    case 2: so = -sn; co = -cs; break;
+    default: so = -cs; co = sn; break;
+    }
+    *s = (float)so;
+    *c = (float)co;
+}
+
+// ---------------------------------------------------------------------------
+// K1: pyramid.  Level 0 = copyMakeBorder(image, REFLECT_101); level l =
+// resize(level l-1, INTER_LINEAR) + copyMakeBorder (ORBextractor.cc:1107-1132).
+// One thread produces 4 consecutive bytes of the padded destination row
+// (one dword store); border pixels recompute the reflected interior pixel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ images, int stride,
+                                                    size_t frame_stride, uint8_t *__restrict__ pyr,
+                                                    PyrGeom G)
+{
+    const LevelGeom L = G.lv[0];
+    const int words = L.pitch >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= words * L.prows) return;
+    const int py = idx / words, pw = idx - py * words;
+    const uint8_t *src = images + (size_t)blockIdx.y * frame_stride;
+    uint8_t *dst = pyr + (size_t)blockIdx.y * G.frame_bytes + L.plane_off;
+    const int sy = reflect101(py - kEdge, L.h);
+    const uint8_t *srow = src + (size_t)sy * stride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int x = pw * 4 + k - kPadL;
+        uint32_t v = 0;
+        if (x >= -kEdge && x < L.w + kEdge) v = srow[reflect101(x, L.w)];
+        out |= v << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(dst + (size_t)py * L.pitch + pw * 4) = out;
+}
+
+// Resize tables (host-built, OpenCV fixed-point): per destination column
+// {xofs, alpha0, alpha1}, per destination row {sy0, sy1, beta0, beta1} as int16.
+__global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, PyrGeom G, int level,
+                                                    const short *__restrict__ tabs)
+{
+    const LevelGeom L = G.lv[level];
+    const LevelGeom P = G.lv[level - 1];
+    const int words = L.pitch >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= words * L.prows) return;
+    const int py = idx / words, pw = idx - py * words;
+    uint8_t *frame = pyr + (size_t)blockIdx.y * G.frame_bytes;
+    const uint8_t *sroi = frame + P.plane_off + (size_t)kEdge * P.pitch + kPadL;
+    uint8_t *dst = frame + L.plane_off;
+    const int dy = reflect101(py - kEdge, L.h);
+    const short *yt = tabs + L.ytab + 4 * dy;
+    const uint8_t *S0 = sroi + (size_t)yt[0] * P.pitch;
+    const uint8_t *S1 = sroi + (size_t)yt[1] * P.pitch;
+    const int b0 = yt[2], b1 = yt[3];
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int x = pw * 4 + k - kPadL;
+        uint32_t v = 0;
+        if (x >= -kEdge && x < L.w + kEdge) {
+            const int dx = reflect101(x, L.w);
+            const short *xt = tabs + L.xtab + 3 * dx;
+            const int sx = xt[0], a0 = xt[1], a1 = xt[2];
+            // sx+1 may be the first border byte when sx == sw-1; a1 is 0 there.
+            const int r0 = S0[sx] * a0 + S0[sx + 1] * a1;
+            const int r1 = S1[sx] * a0 + S1[sx + 1] * a1;
+            v = (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+        }
+        out |= v << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(dst + (size_t)py * L.pitch + pw * 4) = out;
+}
+
+// ---------------------------------------------------------------------------
+// K2+K3: FAST-9/16 + NMS, one workgroup per reference cell (= one cv::FAST call,
+// ORBextractor.cc:789-829).  The (wCell+6)x(hCell+6) sub-image is staged in LDS;
+// the threshold-independent score S = max(dark,bright)-1 is computed for every
+// pixel that is a corner at minThFAST (others hold 0); NMS runs at iniThFAST and
+// falls back to minThFAST when the cell keeps nothing (:812-816).  Neighbours
+// outside the detection rectangle count as 0, exactly like the reference's
+// zero-initialised score rows.  Survivors are emitted in row-major order.
+// ---------------------------------------------------------------------------
+constexpr int kSubMax = 72;            // max (wCell+6), (hCell+6)
+constexpr int kSubStride = kSubMax;    // LDS row stride of the sub-image
+constexpr int kScoreStride = kSubMax;  // detection rect + 1-px zero halo fits (<= 66+2)
+
+__device__ __forceinline__ bool has_arc9(uint32_t m16)
+{
+    uint32_t m = m16 | (m16 << 16);
+    uint32_t a = m & (m >> 1);
+    a &= a >> 2;   // 4 consecutive
+    a &= a >> 4;   // 8 consecutive
+    a &= m >> 8;   // 9 consecutive
+    return (a & 0xffffu) != 0;
+}
+
+__device__ __forceinline__ int fast_score(const uint8_t *c, int v)
+{
+    // ring offsets (dx,dy) k=0..15 as cv::FAST: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)
+    // (0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+    int d[16];
+    d[0] = v - c[3 * kSubStride];      d[1] = v - c[3 * kSubStride + 1];
+    d[2] = v - c[2 * kSubStride + 2];  d[3] = v - c[kSubStride + 3];
+    d[4] = v - c[3];                   d[5] = v - c[-kSubStride + 3];
+    d[6] = v - c[-2 * kSubStride + 2]; d[7] = v - c[-3 * kSubStride + 1];
+    d[8] = v - c[-3 * kSubStride];     d[9] = v - c[-3 * kSubStride - 1];
+    d[10] = v - c[-2 * kSubStride - 2]; d[11] = v - c[-kSubStride - 3];
+    d[12] = v - c[-3];                 d[13] = v - c[kSubStride - 3];
+    d[14] = v - c[2 * kSubStride - 2]; d[15] = v - c[3 * kSubStride - 1];
+    // dark = max over the 16 arcs of min(d), bright = max over arcs of min(-d) = -min over arcs of max(d)
+    int mn2[16], mx2[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+    int mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    int dark = -1000, brightneg = 1000;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        dark = max(dark, mn9);
+        brightneg = min(brightneg, mx9);
+    }
+    return max(dark, -brightneg) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, PyrGeom G,
+                                                    const CellDesc *__restrict__ cells,
+                                                    int *__restrict__ cell_cnt,
+                                                    uint32_t *__restrict__ cell_kp)
+{
+    __shared__ uint8_t simg[kSubMax * kSubStride];
+    __shared__ uint8_t sscore[(kSubMax + 2) * kScoreStride];
+    __shared__ int swave[4];
+    __shared__ int sbase;
+
+    const CellDesc cd = cells[blockIdx.x];
+    const LevelGeom L = G.lv[cd.level];
+    const uint8_t *roi = pyr + (size_t)blockIdx.y * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
+    const int sw = cd.x1 - cd.x0, sh = cd.y1 - cd.y0;  // sub-image size
+    const int dw = sw - 6, dh = sh - 6;                // detection rectangle
+    const int tid = threadIdx.x;
+    const size_t out_cell = (size_t)blockIdx.y * G.ncells_total + blockIdx.x;
+
+    if (dw <= 0 || dh <= 0) {  // cv::FAST on an image narrower than 7 px finds nothing
+        if (tid == 0) cell_cnt[out_cell] = 0;
+        return;
+    }
+    for (int i = tid; i < sw * sh; i += 256) {
+        int y = i / sw, x = i - y * sw;
+        simg[y * kSubStride + x] = roi[(size_t)(cd.y0 + y) * L.pitch + cd.x0 + x];
+    }
+    for (int i = tid; i < (dh + 2) * kScoreStride; i += 256) sscore[i] = 0;
+    __syncthreads();
+
+    const int npix = dw * dh;
+    const int tmin = G.min_th;
+    for (int p = tid; p < npix; p += 256) {
+        int y = p / dw, x = p - y * dw;
+        const uint8_t *c = &simg[(y + 3) * kSubStride + x + 3];
+        const int v = c[0];
+        const int hi = v + tmin, lo = v - tmin;
+        uint32_t mb = 0, md = 0;
+        int ring[16];
+        ring[0] = c[3 * kSubStride];       ring[1] = c[3 * kSubStride + 1];
+        ring[2] = c[2 * kSubStride + 2];   ring[3] = c[kSubStride + 3];
+        ring[4] = c[3];                    ring[5] = c[-kSubStride + 3];
+        ring[6] = c[-2 * kSubStride + 2];  ring[7] = c[-3 * kSubStride + 1];
+        ring[8] = c[-3 * kSubStride];      ring[9] = c[-3 * kSubStride - 1];
+        ring[10] = c[-2 * kSubStride - 2]; ring[11] = c[-kSubStride - 3];
+        ring[12] = c[-3];                  ring[13] = c[kSubStride - 3];
+        ring[14] = c[2 * kSubStride - 2];  ring[15] = c[3 * kSubStride - 1];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            mb |= (uint32_t)(ring[k] > hi) << k;
+            md |= (uint32_t)(ring[k] < lo) << k;
+        }
+        if (has_arc9(mb) || has_arc9(md)) {
+            int s = fast_score(c, v);
+            sscore[(y + 1) * kScoreStride + x + 1] = (uint8_t)min(max(s, 0), 255);
+        }
+    }
+    __syncthreads();
+
+    // NMS at iniTh; count survivors
+    int th = G.ini_th;
+    int cnt = 0;
+    for (int p = tid; p < npix; p += 256) {
+        int y = p / dw, x = p - y * dw;
+        const uint8_t *s = &sscore[(y + 1) * kScoreStride + x + 1];
+        int v = s[0];
+        bool keep = v >= th && v > s[-1] && v > s[1] && v > s[-kScoreStride - 1] && v > s[-kScoreStride] &&
+                    v > s[-kScoreStride + 1] && v > s[kScoreStride - 1] && v > s[kScoreStride] && v > s[kScoreStride + 1];
+        cnt += keep;
+    }
+    int any = __syncthreads_or(cnt);
+    if (!any) th = G.min_th;
+    if (tid == 0) sbase = 0;
+    __syncthreads();
+
+    uint32_t *out = cell_kp + out_cell * G.slot_cap;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int start = 0; start < npix; start += 256) {
+        int p = start + tid;
+        bool keep = false;
+        int x = 0, y = 0, v = 0;
+        if (p < npix) {
+            y = p / dw; x = p - y * dw;
+            const uint8_t *s = &sscore[(y + 1) * kScoreStride + x + 1];
+            v = s[0];
+            keep = v >= th && v > s[-1] && v > s[1] && v > s[-kScoreStride - 1] && v > s[-kScoreStride] &&
+                   v > s[-kScoreStride + 1] && v > s[kScoreStride - 1] && v > s[kScoreStride] && v > s[kScoreStride + 1];
+        }
+        unsigned long long bal = __ballot(keep);
+        if (lane == 0) swave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = sbase;
+        for (int w = 0; w < wave; ++w) off += swave[w];
+        off += __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep && off < G.slot_cap) {
+            // keypoint relative to (minBorderX, minBorderY): FAST coords (x+3,y+3) + cell offset
+            uint32_t kx = (uint32_t)(x + 3 + cd.offx), ky = (uint32_t)(y + 3 + cd.offy);
+            out[off] = kx | (ky << 12) | ((uint32_t)v << 24);
+        }
+        __syncthreads();
+        if (tid == 0) sbase += swave[0] + swave[1] + swave[2] + swave[3];
+        __syncthreads();
+    }
+    if (tid == 0) cell_cnt[out_cell] = min(sbase, G.slot_cap);
+}
+
+// ---------------------------------------------------------------------------
+// K4: DistributeOctTree (ORBextractor.cc:539-763), one workgroup per (level, frame).
+// Parallel restatement: keys never move, each carries the index of
+// the node that owns it; a pass counts the four children of every expandable node
+// with LDS atomics, decides which nodes split (phase 1: all; phase 2: by descending
+// key count, newer node first, until the list reaches N), rebuilds the node table in
+// list order (new children reversed in front, survivors behind) and relabels keys.
+// ---------------------------------------------------------------------------
+template <int MAXN>
+struct OctShared {
+    short x0[2][MAXN], x1[2][MAXN], y0[2][MAXN], y1[2][MAXN];
+    int cnt[2][MAXN];
+    int ccnt[MAXN * 4];
+    int nmap[MAXN];            // survivors: new index; split nodes: 0x40000000 | creation base
+    unsigned short ord[MAXN];  // processing order -> node
+    unsigned short rnk[MAXN];  // node -> processing rank (0xffff: not expandable)
+    int cincl[MAXN];           // inclusive scan of child counts in processing order
+    int scan[8];
+    int vars[8];
+};
+
+template <int MAXN>
+__global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict__ cell_cnt,
+                                                const uint32_t *__restrict__ cell_kp,
+                                                uint32_t *__restrict__ keys_ws,
+                                                unsigned short *__restrict__ node_ws,
+                                                uint32_t *__restrict__ sel_kp,
+                                                int *__restrict__ sel_cnt, int *__restrict__ frame_status)
+{
+    __shared__ OctShared<MAXN> S;
+    const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom L = G.lv[level];
+    uint32_t *keys = keys_ws + (size_t)b * G.cand_cap_total + L.cand_base;
+    unsigned short *knode = node_ws + (size_t)b * G.cand_cap_total + L.cand_base;
+    const int *ccnt_in = cell_cnt + (size_t)b * G.ncells_total + L.cell_base;
+    const uint32_t *ckp_in = cell_kp + ((size_t)b * G.ncells_total + L.cell_base) * G.slot_cap;
+    const int N = L.quota;
+    int tot;
+
+    // ---- gather the per-cell survivor lists into one array, reference order ----
+    int K = 0;
+    for (int c0 = 0; c0 < L.ncells; c0 += 256) {
+        int c = c0 + tid;
+        int n = c < L.ncells ? ccnt_in[c] : 0;
+        int base = block_excl_scan256(n, S.scan, &tot);
+        if (c < L.ncells) S.ccnt[c] = K + base;  // ncells <= MAXN*4 checked on the host
+        K += tot;
+    }
+    __syncthreads();
+    for (int c = tid >> 4; c < L.ncells; c += 16) {  // 16 threads per cell
+        int n = ccnt_in[c], base = S.ccnt[c];
+        for (int i = tid & 15; i < n; i += 16) keys[base + i] = ckp_in[(size_t)c * G.slot_cap + i];
+    }
+    __syncthreads();
+
+    // ---- initial nodes (:543-585) ----
+    const int nIni = L.nIni;
+    const int height = L.maxBY - 16;
+    for (int i = tid; i < nIni; i += 256) {
+        S.x0[0][i] = (short)(int)__fmul_rn(L.hX, (float)i);
+        S.x1[0][i] = (short)(int)__fmul_rn(L.hX, (float)(i + 1));
+        S.y0[0][i] = 0;
+        S.y1[0][i] = (short)height;
+        S.ccnt[i] = 0;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+        float x = (float)(keys[k] & 0xfffu);
+        int bin = (int)__fdiv_rn(x, L.hX);
+        bin = min(bin, nIni - 1);
+        knode[k] = (unsigned short)bin;
+        atomicAdd(&S.ccnt[bin], 1);
+    }
+    __syncthreads();
+    int n = 0;  // list size
+    {
+        // drop empty initial nodes, keep order
+        int carry = 0;
+        for (int i0 = 0; i0 < nIni; i0 += 256) {
+            int i = i0 + tid;
+            int c = i < nIni ? S.ccnt[i] : 0;
+            int pos = carry + block_excl_scan256(c > 0, S.scan, &tot);
+            if (i < nIni) {
+                S.nmap[i] = pos;
+                if (c > 0) {
+                    S.x0[1][pos] = S.x0[0][i]; S.x1[1][pos] = S.x1[0][i];
+                    S.y0[1][pos] = S.y0[0][i]; S.y1[1][pos] = S.y1[0][i];
+                    S.cnt[1][pos] = c;
+                }
+            }
+            carry += tot;
+        }
+        n = carry;
+        __syncthreads();
+        for (int k = tid; k < K; k += 256) knode[k] = (unsigned short)S.nmap[knode[k]];
+        __syncthreads();
+    }
+    int cur = 1;
+    int phase = 1;
+    bool finish = (K == 0);
+
+    while (!finish) {
+        const int prevSize = n;
+        // A: zero child counters
+        for (int i = tid; i < n * 4; i += 256) S.ccnt[i] = 0;
+        __syncthreads();
+        // B: count children of expandable nodes (DivideNode :481-526)
+        for (int k = tid; k < K; k += 256) {
+            int nd = knode[k];
+            if (S.cnt[cur][nd] > 1) {
+                uint32_t kv = keys[k];
+                int x = kv & 0xfff, y = (kv >> 12) & 0xfff;
+                int mx = S.x0[cur][nd] + ((S.x1[cur][nd] - S.x0[cur][nd] + 1) >> 1);
+                int my = S.y0[cur][nd] + ((S.y1[cur][nd] - S.y0[cur][nd] + 1) >> 1);
+                int q = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
+                atomicAdd(&S.ccnt[4 * nd + q], 1);
+            }
+        }
+        __syncthreads();
+        // C: processing rank of every expandable node
+        int m = 0;
+        if (phase == 1) {
+            int carry = 0;
+            for (int i0 = 0; i0 < n; i0 += 256) {
+                int i = i0 + tid;
+                int e = (i < n && S.cnt[cur][i] > 1) ? 1 : 0;
+                int r = carry + block_excl_scan256(e, S.scan, &tot);
+                if (i < n) S.rnk[i] = e ? (unsigned short)r : (unsigned short)0xffff;
+                if (e) S.ord[r] = (unsigned short)i;
+                carry += tot;
+            }
+            m = carry;
+        } else {
+            // (size desc, list position asc): the reference sorts (size, node address) ascending
+            // and walks from the back (:684-685); "newer node first" stands in for the address.
+            int carry = 0;
+            for (int i0 = 0; i0 < n; i0 += 256) {
+                int i = i0 + tid;
+                int e = (i < n && S.cnt[cur][i] > 1) ? 1 : 0;
+                int r = 0;
+                if (e) {
+                    int ci = S.cnt[cur][i];
+                    for (int j = 0; j < n; ++j) {
+                        int cj = S.cnt[cur][j];
+                        r += (cj > 1) && (cj > ci || (cj == ci && j < i));
+                    }
+                    S.rnk[i] = (unsigned short)r;
+                    S.ord[r] = (unsigned short)i;
+                } else if (i < n) S.rnk[i] = 0xffff;
+                int dummy = block_excl_scan256(e, S.scan, &tot);
+                (void)dummy;
+                carry += tot;
+            }
+            m = carry;
+        }
+        __syncthreads();
+        // D: inclusive scan of child counts in processing order; find the break index J
+        int Jfound = 0x7fffffff;
+        {
+            int carry = 0;
+            for (int j0 = 0; j0 < m; j0 += 256) {
+                int j = j0 + tid;
+                int nc = 0;
+                if (j < m) {
+                    int nd = S.ord[j];
+                    nc = (S.ccnt[4 * nd] > 0) + (S.ccnt[4 * nd + 1] > 0) + (S.ccnt[4 * nd + 2] > 0) + (S.ccnt[4 * nd + 3] > 0);
+                }
+                int ex = carry + block_excl_scan256(nc, S.scan, &tot);
+                if (j < m) {
+                    S.cincl[j] = ex + nc;
+                    if (phase == 2 && n + ex + nc - (j + 1) >= N) Jfound = min(Jfound, j);
+                }
+                carry += tot;
+            }
+        }
+        if (tid == 0) S.vars[0] = 0x7fffffff;
+        __syncthreads();
+        if (Jfound != 0x7fffffff) atomicMin(&S.vars[0], Jfound);
+        __syncthreads();
+        int J = S.vars[0];
+        if (J == 0x7fffffff) J = m - 1;
+        const int Gc = (m > 0) ? S.cincl[J] : 0;  // children created this pass
+        // E: build the new table: children reversed in front, survivors behind in order
+        const int nxt = cur ^ 1;
+        int nToExpand = 0;
+        {
+            int carry = 0;
+            for (int i0 = 0; i0 < n; i0 += 256) {
+                int i = i0 + tid;
+                int split = 0;
+                if (i < n) { int r = S.rnk[i]; split = (r != 0xffff && r <= J); }
+                int surv = (i < n && !split) ? 1 : 0;
+                int spos = carry + block_excl_scan256(surv, S.scan, &tot);
+                if (i < n) {
+                    if (surv) {
+                        int ni = Gc + spos;
+                        S.nmap[i] = ni;
+                        S.x0[nxt][ni] = S.x0[cur][i]; S.x1[nxt][ni] = S.x1[cur][i];
+                        S.y0[nxt][ni] = S.y0[cur][i]; S.y1[nxt][ni] = S.y1[cur][i];
+                        S.cnt[nxt][ni] = S.cnt[cur][i];
+                    } else {
+                        int r = S.rnk[i];
+                        int cbase = (r > 0) ? S.cincl[r - 1] : 0;
+                        S.nmap[i] = 0x40000000 | cbase;
+                        int px0 = S.x0[cur][i], px1 = S.x1[cur][i], py0 = S.y0[cur][i], py1 = S.y1[cur][i];
+                        int mx = px0 + ((px1 - px0 + 1) >> 1), my = py0 + ((py1 - py0 + 1) >> 1);
+                        int g = cbase;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            int c = S.ccnt[4 * i + q];
+                            if (c > 0) {
+                                int ni = Gc - 1 - g;
+                                S.x0[nxt][ni] = (short)((q & 1) ? mx : px0);
+                                S.x1[nxt][ni] = (short)((q & 1) ? px1 : mx);
+                                S.y0[nxt][ni] = (short)((q & 2) ? my : py0);
+                                S.y1[nxt][ni] = (short)((q & 2) ? py1 : my);
+                                S.cnt[nxt][ni] = c;
+                                nToExpand += (c > 1);
+                                ++g;
+                            }
+                        }
+                    }
+                }
+                carry += tot;
+            }
+        }
+        __syncthreads();
+        // F: relabel keys
+        for (int k = tid; k < K; k += 256) {
+            int nd = knode[k];
+            int mp = S.nmap[nd];
+            if (mp & 0x40000000) {
+                uint32_t kv = keys[k];
+                int x = kv & 0xfff, y = (kv >> 12) & 0xfff;
+                int mx = S.x0[cur][nd] + ((S.x1[cur][nd] - S.x0[cur][nd] + 1) >> 1);
+                int my = S.y0[cur][nd] + ((S.y1[cur][nd] - S.y0[cur][nd] + 1) >> 1);
+                int q = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
+                int g = mp & 0x3fffffff;
+                for (int qq = 0; qq < q; ++qq) g += (S.ccnt[4 * nd + qq] > 0);
+                knode[k] = (unsigned short)(Gc - 1 - g);
+            } else {
+                knode[k] = (unsigned short)mp;
+            }
+        }
+        // G: bookkeeping (:669-673, :734)
+        if (tid == 0) S.vars[1] = 0;
+        __syncthreads();
+        if (nToExpand) atomicAdd(&S.vars[1], nToExpand);
+        __syncthreads();
+        const int nToExpandAll = S.vars[1];
+        n = Gc + (n - ((m > 0) ? (J + 1) : 0));
+        cur = nxt;
+        if (n >= N || n == prevSize) finish = true;
+        else if (phase == 1 && n + nToExpandAll * 3 > N) phase = 2;
+        __syncthreads();
+    }
+
+    // ---- retain the best key of every node, first index wins ties (:742-760) ----
+    unsigned int *best = reinterpret_cast<unsigned int *>(S.ccnt);
+    for (int i = tid; i < n; i += 256) best[i] = 0;
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+        uint32_t kv = keys[k];
+        atomicMax(&best[knode[k]], ((kv >> 24) << 24) | (0xffffffu - (uint32_t)k));
+    }
+    __syncthreads();
+    uint32_t *out = sel_kp + (size_t)b * G.kp_cap_total + L.kp_base;
+    const int nout = min(n, L.kp_cap);
+    for (int i = tid; i < nout; i += 256) out[i] = keys[0xffffffu - (best[i] & 0xffffffu)];
+    if (tid == 0) {
+        sel_cnt[b * ORBHIP_MAX_LEVELS + level] = nout;
+        if (n > L.kp_cap) atomicExch(&frame_status[b], ORBHIP_E_CAPACITY);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6: GaussianBlur(7x7, sigma 2, REFLECT_101) per level (:1085-1086).  Separable
+// integer kernel through LDS: a 64x32 output tile loads a 70x38 halo tile from the
+// padded plane (the 19-px REFLECT_101 frame supplies the border), row pass to
+// uint16 (<= 255*257), column pass (sum + 2^15) >> 16, saturated.
+// ---------------------------------------------------------------------------
+struct BlurW { int w[7]; };
+struct TileDesc { short level, tx, ty, pad; };
+constexpr int kBlurTW = 64, kBlurTH = 32;
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
+                                              PyrGeom G, const TileDesc *__restrict__ tiles, BlurW W)
+{
+    __shared__ uint8_t sin[(kBlurTH + 6) * (kBlurTW + 8)];
+    __shared__ unsigned short srow[(kBlurTH + 6) * kBlurTW];
+    const TileDesc t = tiles[blockIdx.x];
+    const LevelGeom L = G.lv[t.level];
+    const size_t fo = (size_t)blockIdx.y * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
+    const uint8_t *roi = pyr + fo;
+    uint8_t *out = blur + fo;
+    const int x0 = t.tx * kBlurTW, y0 = t.ty * kBlurTH;
+    const int tid = threadIdx.x;
+    constexpr int SW = kBlurTW + 8;
+    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += 256) {
+        int y = i / (kBlurTW + 6), x = i - y * (kBlurTW + 6);
+        int gx = min(x0 + x - 3, L.w + kEdge - 1), gy = min(y0 + y - 3, L.h + kEdge - 1);
+        sin[y * SW + x] = roi[(ptrdiff_t)gy * L.pitch + gx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
+        int y = i / kBlurTW, x = i - y * kBlurTW;
+        const uint8_t *p = &sin[y * SW + x];
+        int acc = W.w[0] * p[0] + W.w[1] * p[1] + W.w[2] * p[2] + W.w[3] * p[3] + W.w[4] * p[4] + W.w[5] * p[5] + W.w[6] * p[6];
+        srow[i] = (unsigned short)acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < kBlurTH * kBlurTW; i += 256) {
+        int y = i / kBlurTW, x = i - y * kBlurTW;
+        if (x0 + x < L.w && y0 + y < L.h) {
+            const unsigned short *p = &srow[y * kBlurTW + x];
+            int acc = W.w[0] * p[0] + W.w[1] * p[kBlurTW] + W.w[2] * p[2 * kBlurTW] + W.w[3] * p[3 * kBlurTW] +
+                      W.w[4] * p[4 * kBlurTW] + W.w[5] * p[5 * kBlurTW] + W.w[6] * p[6 * kBlurTW];
+            out[(size_t)(y0 + y) * L.pitch + x0 + x] = (uint8_t)min((acc + 32768) >> 16, 255);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K5+K7: IC_Angle (:77-104) + steered rBRIEF (:108-147) + output assembly
+// (:1095-1103), one wavefront per keypoint.  Moments: the 749 disc pixels are
+// spread over the 64 lanes and reduced with shuffles.  Descriptor: test t = 64*j+lane,
+// so four 64-bit ballots are the 32 descriptor bytes (LSB-first) directly.
+// ---------------------------------------------------------------------------
+struct DiscTab { signed char u[768], v[768]; };  // 749 used
+
+__global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restrict__ pyr,
+                                                         const uint8_t *__restrict__ blur, PyrGeom G,
+                                                         const uint32_t *__restrict__ sel_kp,
+                                                         const int *__restrict__ sel_cnt,
+                                                         const DiscTab *__restrict__ disc,
+                                                         const int *__restrict__ pattern,
+                                                         orbhip_keypoint *__restrict__ out_kp,
+                                                         uint8_t *__restrict__ out_desc, int cap,
+                                                         int *__restrict__ out_n, int *__restrict__ status)
+{
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (slot >= G.kp_cap_total) return;
+    int level = 0;
+    for (int l = 1; l < G.nlevels; ++l) if (slot >= G.lv[l].kp_base) level = l;
+    const LevelGeom L = G.lv[level];
+    const int i = slot - L.kp_base;
+    const int *cnts = sel_cnt + b * ORBHIP_MAX_LEVELS;
+    int before = 0, total = 0;
+    for (int l = 0; l < G.nlevels; ++l) { int c = cnts[l]; if (l < level) before += c; total += c; }
+    if (slot == 0 && lane == 0) {
+        out_n[b] = min(total, cap);
+        if (total > cap && status) atomicExch(&status[b], ORBHIP_E_CAPACITY);
+    }
+    if (i >= cnts[level]) return;
+    const int oidx = before + i;
+    if (oidx >= cap) return;
+
+    const uint32_t kv = sel_kp[(size_t)b * G.kp_cap_total + slot];
+    const int kx = (int)(kv & 0xfff) + 16, ky = (int)((kv >> 12) & 0xfff) + 16;  // + minBorder (:843-844)
+    const int resp = (int)(kv >> 24);
+    const size_t fo = (size_t)b * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
+    const uint8_t *c = pyr + fo + (size_t)ky * L.pitch + kx;
+
+    int m10 = 0, m01 = 0;
+    for (int t = lane; t < 749; t += 64) {
+        int u = disc->u[t], v = disc->v[t];
+        int I = c[v * L.pitch + u];
+        m10 += u * I;
+        m01 += v * I;
+    }
+    m10 = wave_reduce_add(m10);
+    m01 = wave_reduce_add(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, bsn;
+    det_sincos(__fmul_rn(angle, factorPI), &a, &bsn);
+    const uint8_t *cb = blur + fo + (size_t)ky * L.pitch + kx;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pw = pattern[j * 64 + lane];
+        const float px0 = (float)(signed char)(pw & 0xff), py0 = (float)(signed char)((pw >> 8) & 0xff);
+        const float px1 = (float)(signed char)((pw >> 16) & 0xff), py1 = (float)(signed char)((pw >> 24) & 0xff);
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, bsn), __fmul_rn(py0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, bsn)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, bsn), __fmul_rn(py1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, bsn)));
+        const int t0 = cb[r0 * L.pitch + c0], t1 = cb[r1 * L.pitch + c1];
+        bits[j] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        reinterpret_cast<unsigned long long *>(out_desc + ((size_t)b * cap + oidx) * 32)[lane] = v;
+    }
+    if (lane == 0) {
+        orbhip_keypoint kp;
+        float fx = (float)kx, fy = (float)ky;
+        if (level != 0) { fx = __fmul_rn(fx, L.scale); fy = __fmul_rn(fy, L.scale); }
+        kp.x = fx; kp.y = fy; kp.size = (float)L.patch; kp.angle = angle; kp.response = (float)resp;
+        kp.octave = level; kp.class_id = -1;
+        out_kp[(size_t)b * cap + oidx] = kp;
+    }
+}
+
+__global__ void k_zero_status(int *status, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) status[i] = 0;
+}
+
+}  // namespace orbhip
+
+// ===========================================================================
+// host side
+// ===========================================================================
+using namespace orbhip;
+
+struct orbhip_extractor {
+    int nfeatures = 0;
+    double scaleFactor = 1.2;
+    int nlevels = 8, iniTh = 20, minTh = 7, device = 0;
+    float sf[ORBHIP_MAX_LEVELS], isf[ORBHIP_MAX_LEVELS], sig2[ORBHIP_MAX_LEVELS], isig2[ORBHIP_MAX_LEVELS];
+    int nfeat[ORBHIP_MAX_LEVELS];
+    int umax[kHalfPatch + 1];
+    BlurW blurw;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool profiling = false, have_times = false;
+    float times[6] = {0, 0, 0, 0, 0, 0};
+
+    // geometry (bound to an image size)
+    bool bound = false;
+    PyrGeom G;
+    std::vector<CellDesc> cells;
+    std::vector<TileDesc> tiles;
+    int octree_maxn = 512;
+    CellDesc *d_cells = nullptr;
+    TileDesc *d_tiles = nullptr;
+    short *d_tabs = nullptr;
+    DiscTab *d_disc = nullptr;
+    int *d_pattern = nullptr;
+
+    // per-batch-capacity buffers
+    int batch_cap = 0;
+    int last_batch = 0;
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+    int *d_cell_cnt = nullptr;
+    uint32_t *d_cell_kp = nullptr;
+    uint32_t *d_keys = nullptr;
+    unsigned short *d_knode = nullptr;
+    uint32_t *d_sel = nullptr;
+    int *d_sel_cnt = nullptr;
+    int *d_status = nullptr;
+    // staging for the host-pointer API
+    uint8_t *d_img = nullptr; size_t d_img_bytes = 0;
+    orbhip_keypoint *d_okp = nullptr; uint8_t *d_odesc = nullptr; int *d_on = nullptr;
+    int out_cap = 0, out_batch = 0;
+};
+
+static int cv_round(double v) { return (int)lrint(v); }
+
+static void free_geometry(orbhip_extractor *e)
+{
+    hipFree(e->d_cells); hipFree(e->d_tiles); hipFree(e->d_tabs);
+    e->d_cells = nullptr; e->d_tiles = nullptr; e->d_tabs = nullptr;
+    e->bound = false;
+}
+static void free_batch(orbhip_extractor *e)
+{
+    hipFree(e->d_pyr); hipFree(e->d_blur); hipFree(e->d_cell_cnt); hipFree(e->d_cell_kp);
+    hipFree(e->d_keys); hipFree(e->d_knode); hipFree(e->d_sel); hipFree(e->d_sel_cnt); hipFree(e->d_status);
+    e->d_pyr = e->d_blur = nullptr; e->d_cell_cnt = nullptr; e->d_cell_kp = nullptr; e->d_keys = nullptr;
+    e->d_knode = nullptr; e->d_sel = nullptr; e->d_sel_cnt = nullptr; e->d_status = nullptr;
+    e->batch_cap = 0;
+}
+
+// Bind the handle to an image size: level geometry (:1111-1113), cell table (:769-829),
+// OpenCV resize tables, blur tiles.
+static int bind_geometry(orbhip_extractor *e, int rows, int cols)
+{
+    if (e->bound && e->G.rows == rows && e->G.cols == cols) return ORBHIP_OK;
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    free_geometry(e);
+    free_batch(e);
+    PyrGeom &G = e->G;
+    memset(&G, 0, sizeof(G));
+    G.nlevels = e->nlevels; G.rows = rows; G.cols = cols; G.ini_th = e->iniTh; G.min_th = e->minTh;
+    e->cells.clear(); e->tiles.clear();
+    std::vector<short> tabs;
+    unsigned off = 0;
+    int kp_base = 0, cand_base = 0, slot_cap = 1;
+    for (int l = 0; l < e->nlevels; ++l) {
+        LevelGeom &L = G.lv[l];
+        const float scale = e->isf[l];
+        L.w = cv_round((float)cols * scale);
+        L.h = cv_round((float)rows * scale);
+        if (L.w < 2 * kEdge + 2 || L.h < 2 * kEdge + 2 || L.w > 4000 || L.h > 4000) {
+            set_error("level %d is %dx%d: unsupported (need 40..4000 px per side)", l, L.w, L.h);
+            return ORBHIP_E_SIZE;
+        }
+        L.pitch = (kPadL + L.w + kEdge + 63) & ~63;
+        L.prows = L.h + 2 * kEdge;
+        L.plane_off = off;
+        off += (unsigned)L.pitch * L.prows;
+        off = (off + 255u) & ~255u;
+        L.maxBX = L.w - kEdge + 3; L.maxBY = L.h - kEdge + 3;
+        L.quota = e->nfeat[l];
+        L.patch = (int)(kPatchSize * e->sf[l]);
+        L.scale = e->sf[l];
+        // cells (:781-829)
+        const int minB = kEdge - 3;
+        const float width = (float)(L.maxBX - minB), height = (float)(L.maxBY - minB);
+        const float W = 30;
+        const int nCols = (int)(width / W), nRows = (int)(height / W);
+        L.cell_base = (int)e->cells.size();
+        if (nCols >= 1 && nRows >= 1) {
+            const int wCell = (int)ceilf(width / nCols), hCell = (int)ceilf(height / nRows);
+            if (wCell + 6 > kSubMax || hCell + 6 > kSubMax) { set_error("cell too large"); return ORBHIP_E_SIZE; }
+            for (int i = 0; i < nRows; ++i) {
+                const float iniY = (float)(minB + i * hCell);
+                float maxY = iniY + hCell + 6;
+                if (iniY >= L.maxBY - 3) continue;
+                if (maxY > L.maxBY) maxY = (float)L.maxBY;
+                for (int j = 0; j < nCols; ++j) {
+                    const float iniX = (float)(minB + j * wCell);
+                    float maxX = iniX + wCell + 6;
+                    if (iniX >= L.maxBX - 6) continue;
+                    if (maxX > L.maxBX) maxX = (float)L.maxBX;
+                    CellDesc c;
+                    c.level = (short)l; c.x0 = (short)iniX; c.y0 = (short)iniY; c.x1 = (short)maxX; c.y1 = (short)maxY;
+                    c.offx = (short)(j * wCell); c.offy = (short)(i * hCell); c.pad = 0;
+                    e->cells.push_back(c);
+                    int dw = c.x1 - c.x0 - 6, dh = c.y1 - c.y0 - 6;
+                    if (dw > 0 && dh > 0) slot_cap = std::max(slot_cap, ((dw + 1) / 2) * ((dh + 1) / 2));
+                }
+            }
+        }
+        L.ncells = (int)e->cells.size() - L.cell_base;
+        // octree roots (:543-545)
+        const int bw = L.maxBX - minB, bh = L.maxBY - minB;
+        int nIni = bh > 0 ? (int)roundf((float)bw / bh) : 0;
+        if (nIni < 1) nIni = 1;  // the reference divides by zero for tall images; one root instead
+        L.nIni = nIni;
+        L.hX = (float)bw / nIni;
+        L.kp_cap = std::max(L.quota + 3, 4 * nIni);
+        L.kp_base = kp_base; kp_base += L.kp_cap;
+        // resize tables for level l (from level l-1), OpenCV fixed-point arithmetic
+        L.xtab = (int)tabs.size();
+        if (l > 0) {
+            const int sw = G.lv[l - 1].w, shh = G.lv[l - 1].h;
+            const double scale_x = 1. / ((double)L.w / sw), scale_y = 1. / ((double)L.h / shh);
+            for (int dx = 0; dx < L.w; ++dx) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = (int)floor(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+                tabs.push_back((short)sx);
+                tabs.push_back((short)cv_round((1.f - fx) * 2048));
+                tabs.push_back((short)cv_round(fx * 2048));
+            }
+            if (tabs.size() & 1) tabs.push_back(0);
+            L.ytab = (int)tabs.size();
+            for (int dy = 0; dy < L.h; ++dy) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = (int)floor(fy);
+                fy -= sy;
+                int sy0 = sy < 0 ? 0 : (sy < shh ? sy : shh - 1);
+                int sy1 = sy + 1 < 0 ? 0 : (sy + 1 < shh ? sy + 1 : shh - 1);
+                tabs.push_back((short)sy0); tabs.push_back((short)sy1);
+                tabs.push_back((short)cv_round((1.f - fy) * 2048));
+                tabs.push_back((short)cv_round(fy * 2048));
+            }
+        }
+        // blur tiles
+        for (int ty = 0; ty * kBlurTH < L.h; ++ty)
+            for (int tx = 0; tx * kBlurTW < L.w; ++tx) {
+                TileDesc t; t.level = (short)l; t.tx = (short)tx; t.ty = (short)ty; t.pad = 0;
+                e->tiles.push_back(t);
+            }
+    }
+    G.frame_bytes = off;
+    G.ncells_total = (int)e->cells.size();
+    G.slot_cap = slot_cap;
+    G.kp_cap_total = kp_base;
+    int maxn = 0;
+    for (int l = 0; l < e->nlevels; ++l) {
+        LevelGeom &L = G.lv[l];
+        L.cand_base = cand_base;
+        L.cand_cap = L.ncells * slot_cap;
+        cand_base += L.cand_cap;
+        maxn = std::max(maxn, std::max(L.kp_cap + 4, (L.ncells + 3) / 4));
+    }
+    G.cand_cap_total = std::max(cand_base, 1);
+    if (maxn <= 512) e->octree_maxn = 512;
+    else if (maxn <= 2048) e->octree_maxn = 2048;
+    else { set_error("nfeatures too large for the octree kernel (per-level cap %d > 2048)", maxn); return ORBHIP_E_ARG; }
+    if (G.ncells_total == 0) { /* tiny image: no FAST cells anywhere; still a valid (empty) result */ }
+    if (!e->cells.empty()) {
+        ORBHIP_HIP_CHECK(hipMalloc(&e->d_cells, e->cells.size() * sizeof(CellDesc)));
+        ORBHIP_HIP_CHECK(hipMemcpy(e->d_cells, e->cells.data(), e->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+    }
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_tiles, e->tiles.size() * sizeof(TileDesc)));
+    ORBHIP_HIP_CHECK(hipMemcpy(e->d_tiles, e->tiles.data(), e->tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    if (tabs.empty()) tabs.push_back(0);
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_tabs, tabs.size() * sizeof(short)));
+    ORBHIP_HIP_CHECK(hipMemcpy(e->d_tabs, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice));
+    e->bound = true;
+    return ORBHIP_OK;
+}
+
+static int ensure_batch(orbhip_extractor *e, int batch)
+{
+    if (batch <= e->batch_cap) return ORBHIP_OK;
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    free_batch(e);
+    const PyrGeom &G = e->G;
+    const size_t B = (size_t)batch;
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_pyr, B * G.frame_bytes));
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_blur, B * G.frame_bytes));
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_cell_cnt, B * std::max(G.ncells_total, 1) * sizeof(int)));
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_cell_kp, B * std::max(G.ncells_total, 1) * G.slot_cap * sizeof(uint32_t)));
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_keys, B * G.cand_cap_total * sizeof(uint32_t)));
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_knode, B * G.cand_cap_total * sizeof(unsigned short)));
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_sel, B * G.kp_cap_total * sizeof(uint32_t)));
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_sel_cnt, B * ORBHIP_MAX_LEVELS * sizeof(int)));
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_status, B * sizeof(int)));
+    e->batch_cap = batch;
+    return ORBHIP_OK;
+}
+
+static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int batch, int stride,
+                           size_t frame_stride, orbhip_keypoint *d_kps, uint8_t *d_desc, int cap,
+                           int *d_n, int *d_status)
+{
+    const PyrGeom &G = e->G;
+    hipStream_t s = e->stream;
+    const bool prof = e->profiling;
+    int *status = d_status ? d_status : e->d_status;
+    hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
+    if (prof) hipEventRecord(e->ev[0], s);
+    {
+        const LevelGeom &L = G.lv[0];
+        int n = (L.pitch >> 2) * L.prows;
+        hipLaunchKernelGGL(k_pyr_level0, dim3((n + 255) / 256, batch), dim3(256), 0, s, d_images, stride,
+                           frame_stride, e->d_pyr, G);
+        for (int l = 1; l < G.nlevels; ++l) {
+            const LevelGeom &Ll = G.lv[l];
+            int nl = (Ll.pitch >> 2) * Ll.prows;
+            hipLaunchKernelGGL(k_pyr_resize, dim3((nl + 255) / 256, batch), dim3(256), 0, s, e->d_pyr, G, l, e->d_tabs);
+        }
+    }
+    if (prof) hipEventRecord(e->ev[1], s);
+    if (G.ncells_total > 0)
+        hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, batch), dim3(256), 0, s, e->d_pyr, G, e->d_cells,
+                           e->d_cell_cnt, e->d_cell_kp);
+    if (prof) hipEventRecord(e->ev[2], s);
+    if (e->octree_maxn == 512)
+        hipLaunchKernelGGL(k_octree<512>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
+                           e->d_keys, e->d_knode, e->d_sel, e->d_sel_cnt, status);
+    else
+        hipLaunchKernelGGL(k_octree<2048>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
+                           e->d_keys, e->d_knode, e->d_sel, e->d_sel_cnt, status);
+    if (prof) hipEventRecord(e->ev[3], s);
+    hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, e->d_pyr, e->d_blur, G,
+                       e->d_tiles, e->blurw);
+    if (prof) hipEventRecord(e->ev[4], s);
+    hipLaunchKernelGGL(k_orient_describe, dim3((G.kp_cap_total + 3) / 4, batch), dim3(256), 0, s, e->d_pyr, e->d_blur,
+                       G, e->d_sel, e->d_sel_cnt, e->d_disc, e->d_pattern, d_kps, d_desc, cap, d_n, status);
+    if (prof) { hipEventRecord(e->ev[5], s); e->have_times = true; }
+    e->last_batch = batch;
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" {
+
+const char *orbhip_last_error(void) { return g_err; }
+
+int orbhip_device_count(int *count)
+{
+    if (!count) return ORBHIP_E_ARG;
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) { *count = 0; set_error("hipGetDeviceCount: %s", hipGetErrorString(err)); return ORBHIP_E_NODEVICE; }
+    *count = n;
+    return ORBHIP_OK;
+}
+
+int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
+                            int device, orbhip_extractor **out)
+{
+    if (!out || nlevels < 1 || nlevels > ORBHIP_MAX_LEVELS || nfeatures < 0 || !(scale_factor > 1.0f)) {
+        set_error("orbhip_extractor_create: bad argument");
+        return ORBHIP_E_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_error("no HIP device %d (found %d)", device, ndev);
+        return ORBHIP_E_NODEVICE;
+    }
+    orbhip_extractor *e = new (std::nothrow) orbhip_extractor();
+    if (!e) return ORBHIP_E_ARG;
+    e->nfeatures = nfeatures; e->scaleFactor = scale_factor; e->nlevels = nlevels;
+    e->iniTh = std::min(std::max(ini_th, 0), 255); e->minTh = std::min(std::max(min_th, 0), 255);
+    e->device = device;
+    // scale tables and quotas, src/ORBextractor.cc:415-446
+    e->sf[0] = 1.0f; e->sig2[0] = 1.0f;
+    for (int i = 1; i < nlevels; ++i) { e->sf[i] = (float)(e->sf[i - 1] * e->scaleFactor); e->sig2[i] = e->sf[i] * e->sf[i]; }
+    for (int i = 0; i < nlevels; ++i) { e->isf[i] = 1.0f / e->sf[i]; e->isig2[i] = 1.0f / e->sig2[i]; }
+    float factor = (float)(1.0f / e->scaleFactor);
+    float nDesired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; ++l) { e->nfeat[l] = cv_round(nDesired); sum += e->nfeat[l]; nDesired *= factor; }
+    e->nfeat[nlevels - 1] = std::max(nfeatures - sum, 0);
+    // umax, :454-469
+    int v, v0, vmax = (int)floor(kHalfPatch * sqrtf(2.f) / 2 + 1), vmin = (int)ceil(kHalfPatch * sqrtf(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (v = 0; v <= vmax; ++v) e->umax[v] = cv_round(sqrt(hp2 - v * v));
+    for (v = kHalfPatch, v0 = 0; v >= vmin; --v) { while (e->umax[v0] == e->umax[v0 + 1]) ++v0; e->umax[v] = v0; ++v0; }
+    const int bw[7] = {18, 34, 49, 55, 49, 34, 18};
+    for (int i = 0; i < 7; ++i) e->blurw.w[i] = bw[i];
+
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipSetDevice/hipStreamCreate failed");
+        delete e;
+        return ORBHIP_E_HIP;
+    }
+    for (int i = 0; i < 6; ++i) hipEventCreate(&e->ev[i]);
+    // disc offsets in the reference's traversal order (order is irrelevant for integer sums)
+    DiscTab dt; memset(&dt, 0, sizeof(dt));
+    int nd = 0;
+    for (int u = -kHalfPatch; u <= kHalfPatch; ++u) { dt.u[nd] = (signed char)u; dt.v[nd] = 0; ++nd; }
+    for (int vv = 1; vv <= kHalfPatch; ++vv) {
+        int d = e->umax[vv];
+        for (int u = -d; u <= d; ++u) {
+            dt.u[nd] = (signed char)u; dt.v[nd] = (signed char)vv; ++nd;
+            dt.u[nd] = (signed char)u; dt.v[nd] = (signed char)-vv; ++nd;
+        }
+    }
+    if (nd != 749) { set_error("disc table has %d entries", nd); orbhip_extractor_destroy(e); return ORBHIP_E_ARG; }
+    if (hipMalloc(&e->d_disc, sizeof(DiscTab)) != hipSuccess || hipMalloc(&e->d_pattern, 256 * sizeof(int)) != hipSuccess) {
+        set_error("hipMalloc failed"); orbhip_extractor_destroy(e); return ORBHIP_E_HIP;
+    }
+    hipMemcpy(e->d_disc, &dt, sizeof(dt), hipMemcpyHostToDevice);
+    hipMemcpy(e->d_pattern, orbhip_rbrief_pattern, 1024, hipMemcpyHostToDevice);
+    *out = e;
+    return ORBHIP_OK;
+}
+
+void orbhip_extractor_destroy(orbhip_extractor *e)
+{
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    free_geometry(e);
+    free_batch(e);
+    hipFree(e->d_disc); hipFree(e->d_pattern); hipFree(e->d_img); hipFree(e->d_okp); hipFree(e->d_odesc); hipFree(e->d_on);
+    for (int i = 0; i < 6; ++i) if (e->ev[i]) hipEventDestroy(e->ev[i]);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int orbhip_extractor_levels(const orbhip_extractor *e) { return e ? e->nlevels : ORBHIP_E_ARG; }
+
+int orbhip_extractor_tables(const orbhip_extractor *e, float *scale, float *inv_scale, float *sigma2,
+                            float *inv_sigma2, int32_t *feat)
+{
+    if (!e) return ORBHIP_E_ARG;
+    for (int i = 0; i < e->nlevels; ++i) {
+        if (scale) scale[i] = e->sf[i];
+        if (inv_scale) inv_scale[i] = e->isf[i];
+        if (sigma2) sigma2[i] = e->sig2[i];
+        if (inv_sigma2) inv_sigma2[i] = e->isig2[i];
+        if (feat) feat[i] = e->nfeat[i];
+    }
+    return ORBHIP_OK;
+}
+
+int orbhip_extractor_capacity(orbhip_extractor *e, int rows, int cols, int *cap)
+{
+    if (!e || !cap || rows <= 0 || cols <= 0) return ORBHIP_E_ARG;
+    int rc = bind_geometry(e, rows, cols);
+    if (rc) return rc;
+    *cap = e->G.kp_cap_total;
+    return ORBHIP_OK;
+}
+
+int orbhip_extractor_set_blur_kernel(orbhip_extractor *e, const int32_t w[7])
+{
+    if (!e || !w) return ORBHIP_E_ARG;
+    int s = 0;
+    for (int i = 0; i < 7; ++i) { if (w[i] < 0 || w[i] > 256) return ORBHIP_E_ARG; s += w[i]; }
+    if (s > 257) { set_error("blur weights sum %d > 257 overflows the uint16 row pass", s); return ORBHIP_E_ARG; }
+    for (int i = 0; i < 7; ++i) e->blurw.w[i] = w[i];
+    return ORBHIP_OK;
+}
+
+int orbhip_extract_batch_device(orbhip_extractor *e, const void *d_images, int batch, int rows, int cols,
+                                int stride, size_t frame_stride, void *d_kps, void *d_desc, int cap,
+                                void *d_n, void *d_status)
+{
+    if (!e || !d_images || !d_kps || !d_desc || !d_n || batch <= 0 || rows <= 0 || cols <= 0 || stride < cols || cap <= 0) {
+        set_error("orbhip_extract_batch_device: bad argument");
+        return ORBHIP_E_ARG;
+    }
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    int rc = bind_geometry(e, rows, cols);
+    if (rc) return rc;
+    rc = ensure_batch(e, batch);
+    if (rc) return rc;
+    return launch_pipeline(e, (const uint8_t *)d_images, batch, stride, frame_stride, (orbhip_keypoint *)d_kps,
+                           (uint8_t *)d_desc, cap, (int *)d_n, (int *)d_status);
+}
+
+int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, int rows, int cols, int stride,
+                         size_t frame_stride, orbhip_keypoint *kps, uint8_t *desc, int cap, int32_t *n)
+{
+    if (!e || !kps || !desc || !n || batch <= 0 || cap <= 0) { set_error("orbhip_extract_batch: bad argument"); return ORBHIP_E_ARG; }
+    if (!images || rows <= 0 || cols <= 0) {  // empty image: silent return (:1046-1047)
+        for (int b = 0; b < batch; ++b) n[b] = 0;
+        return ORBHIP_OK;
+    }
+    if (stride < cols) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    int rc = bind_geometry(e, rows, cols);
+    if (rc) return rc;
+    // staging buffers
+    const size_t img_bytes = (size_t)batch * rows * cols;
+    if (img_bytes > e->d_img_bytes) {
+        hipFree(e->d_img); e->d_img = nullptr; e->d_img_bytes = 0;
+        ORBHIP_HIP_CHECK(hipMalloc(&e->d_img, img_bytes));
+        e->d_img_bytes = img_bytes;
+    }
+    if (cap > e->out_cap || batch > e->out_batch) {
+        hipFree(e->d_okp); hipFree(e->d_odesc); hipFree(e->d_on);
+        e->d_okp = nullptr; e->d_odesc = nullptr; e->d_on = nullptr;
+        int oc = std::max(cap, e->out_cap), ob = std::max(batch, e->out_batch);
+        ORBHIP_HIP_CHECK(hipMalloc(&e->d_okp, (size_t)ob * oc * sizeof(orbhip_keypoint)));
+        ORBHIP_HIP_CHECK(hipMalloc(&e->d_odesc, (size_t)ob * oc * 32));
+        ORBHIP_HIP_CHECK(hipMalloc(&e->d_on, (size_t)ob * sizeof(int)));
+        e->out_cap = oc; e->out_batch = ob;
+    }
+    for (int b = 0; b < batch; ++b)
+        ORBHIP_HIP_CHECK(hipMemcpy2DAsync(e->d_img + (size_t)b * rows * cols, cols, images + b * frame_stride, stride,
+                                          cols, rows, hipMemcpyHostToDevice, e->stream));
+    rc = ensure_batch(e, batch);
+    if (rc) return rc;
+    rc = launch_pipeline(e, e->d_img, batch, cols, (size_t)rows * cols, e->d_okp, e->d_odesc, cap, e->d_on, nullptr);
+    if (rc) return rc;
+    std::vector<int> st(batch);
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(n, e->d_on, batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(st.data(), e->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    for (int b = 0; b < batch; ++b) {
+        if (st[b] != 0) { set_error("frame %d: capacity exceeded (cap %d)", b, cap); return ORBHIP_E_CAPACITY; }
+        if (n[b] > 0) {
+            ORBHIP_HIP_CHECK(hipMemcpyAsync(kps + (size_t)b * cap, e->d_okp + (size_t)b * cap, (size_t)n[b] * sizeof(orbhip_keypoint),
+                                            hipMemcpyDeviceToHost, e->stream));
+            ORBHIP_HIP_CHECK(hipMemcpyAsync(desc + (size_t)b * cap * 32, e->d_odesc + (size_t)b * cap * 32, (size_t)n[b] * 32,
+                                            hipMemcpyDeviceToHost, e->stream));
+        }
+    }
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return ORBHIP_OK;
+}
+
+int orbhip_extract(orbhip_extractor *e, const uint8_t *image, int rows, int cols, int stride,
+                   orbhip_keypoint *kps, uint8_t *desc, int cap, int *n)
+{
+    if (!n) return ORBHIP_E_ARG;
+    int32_t nn = 0;
+    int rc = orbhip_extract_batch(e, image, 1, rows, cols, stride, 0, kps, desc, cap, &nn);
+    *n = nn;
+    return rc;
+}
+
+int orbhip_extractor_sync(orbhip_extractor *e)
+{
+    if (!e) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return ORBHIP_OK;
+}
+
+void *orbhip_extractor_stream(orbhip_extractor *e) { return e ? (void *)e->stream : nullptr; }
+
+int orbhip_pyramid_level(orbhip_extractor *e, int frame, int level, int *rows, int *cols, int *stride, const void **d_roi)
+{
+    if (!e || !e->bound || frame < 0 || frame >= e->last_batch || level < 0 || level >= e->nlevels) return ORBHIP_E_ARG;
+    const LevelGeom &L = e->G.lv[level];
+    if (rows) *rows = L.h;
+    if (cols) *cols = L.w;
+    if (stride) *stride = L.pitch;
+    if (d_roi) *d_roi = e->d_pyr + (size_t)frame * e->G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
+    return ORBHIP_OK;
+}
+
+static int download_plane(orbhip_extractor *e, const uint8_t *base, int frame, int level, int with_border, uint8_t *dst, int dst_stride)
+{
+    if (!e || !e->bound || !dst || frame < 0 || frame >= e->last_batch || level < 0 || level >= e->nlevels) return ORBHIP_E_ARG;
+    const LevelGeom &L = e->G.lv[level];
+    const int bo = with_border ? kEdge : 0;
+    const int w = L.w + 2 * bo, h = L.h + 2 * bo;
+    if (dst_stride < w) return ORBHIP_E_ARG;
+    const uint8_t *src = base + (size_t)frame * e->G.frame_bytes + L.plane_off + (size_t)(kEdge - bo) * L.pitch + (kPadL - bo);
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    ORBHIP_HIP_CHECK(hipMemcpy2D(dst, dst_stride, src, L.pitch, w, h, hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+int orbhip_pyramid_level_download(orbhip_extractor *e, int frame, int level, int with_border, uint8_t *dst, int dst_stride)
+{
+    return download_plane(e, e ? e->d_pyr : nullptr, frame, level, with_border, dst, dst_stride);
+}
+
+int orbhip_blurred_level_download(orbhip_extractor *e, int frame, int level, uint8_t *dst, int dst_stride)
+{
+    return download_plane(e, e ? e->d_blur : nullptr, frame, level, 0, dst, dst_stride);
+}
+
+int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *x, int32_t *y, int32_t *score, int cap, int *n)
+{
+    if (!e || !e->bound || !n || frame < 0 || frame >= e->last_batch || level < 0 || level >= e->nlevels) return ORBHIP_E_ARG;
+    const PyrGeom &G = e->G;
+    const LevelGeom &L = G.lv[level];
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    std::vector<int> cnt(std::max(L.ncells, 1));
+    std::vector<uint32_t> kp((size_t)std::max(L.ncells, 1) * G.slot_cap);
+    if (L.ncells > 0) {
+        ORBHIP_HIP_CHECK(hipMemcpy(cnt.data(), e->d_cell_cnt + (size_t)frame * G.ncells_total + L.cell_base, L.ncells * sizeof(int), hipMemcpyDeviceToHost));
+        ORBHIP_HIP_CHECK(hipMemcpy(kp.data(), e->d_cell_kp + ((size_t)frame * G.ncells_total + L.cell_base) * G.slot_cap,
+                                   (size_t)L.ncells * G.slot_cap * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    int k = 0;
+    for (int c = 0; c < L.ncells; ++c)
+        for (int i = 0; i < cnt[c]; ++i) {
+            uint32_t v = kp[(size_t)c * G.slot_cap + i];
+            if (k < cap) { if (x) x[k] = v & 0xfff; if (y) y[k] = (v >> 12) & 0xfff; if (score) score[k] = v >> 24; }
+            ++k;
+        }
+    *n = k;
+    return k > cap ? ORBHIP_E_CAPACITY : ORBHIP_OK;
+}
+
+int orbhip_extractor_set_profiling(orbhip_extractor *e, int on)
+{
+    if (!e) return ORBHIP_E_ARG;
+    e->profiling = on != 0;
+    e->have_times = false;
+    return ORBHIP_OK;
+}
+
+int orbhip_extractor_stage_times(orbhip_extractor *e, float us[6])
+{
+    if (!e || !us || !e->have_times) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    ORBHIP_HIP_CHECK(hipEventSynchronize(e->ev[5]));
+    for (int i = 0; i < 5; ++i) {
+        float ms = 0;
+        ORBHIP_HIP_CHECK(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+        us[i] = ms * 1000.f;
+    }
+    float ms = 0;
+    ORBHIP_HIP_CHECK(hipEventElapsedTime(&ms, e->ev[0], e->ev[5]));
+    us[5] = ms * 1000.f;
+    return ORBHIP_OK;
+}
+
+}  // extern "C"
