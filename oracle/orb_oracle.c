@@ -542,13 +542,19 @@ static float ic_angle(const uint8_t *center, int step, const int *u_max)
     return oracle_fast_atan2((float)m_01, (float)m_10);
 }
 
+/* Test hook: evaluate the descriptor steering with this platform's libm cosf/sinf instead of
+ * det_sincos, to measure how far the deterministic choice is from a glibc build. */
+static int g_use_libm_sincos = 0;
+void oracle_use_libm_sincos(int on) { g_use_libm_sincos = on; }
+
 /* computeOrbDescriptor :108-147 */
 static void orb_descriptor(float kp_angle, const uint8_t *center, int step, uint8_t *desc)
 {
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float angle = kp_angle * factorPI;
     float a, b;
-    oracle_det_sincos(angle, &a, &b);
+    if (g_use_libm_sincos) { a = cosf(angle); b = sinf(angle); }
+    else oracle_det_sincos(angle, &a, &b);
     const signed char *pat = oracle_rbrief_pattern;
     for (int i = 0; i < 32; ++i, pat += 32) {
         int val = 0;

@@ -79,6 +79,7 @@ int oracle_level_keypoints(const oracle_extractor *e, int level, const oracle_kp
 int oracle_cvround(double v);
 float oracle_fast_atan2(float y, float x);
 void oracle_det_sincos(float angle_rad, float *c, float *s);
+void oracle_use_libm_sincos(int on); /* test hook: steer descriptors with libm cosf/sinf */
 void oracle_resize_linear(const uint8_t *src, int sstep, int sw, int sh,
                           uint8_t *dst, int dstep, int dw, int dh);
 void oracle_gauss7(const uint8_t *src, int sstep, int w, int h, uint8_t *dst, int dstep);

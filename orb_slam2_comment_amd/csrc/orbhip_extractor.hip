@@ -7,7 +7,7 @@
 // planes) stays resident in HBM between the stages.  Integer/bitwise path:
 // no MFMA.  All float arithmetic that feeds a rounding decision is written
 // with explicit, un-contracted operations.
-#include "orbhip_common.h"
+#include "orbhip_internal.h"
 #include "rbrief_pattern.h"
 
 #include <cfloat>
@@ -627,9 +627,6 @@ __global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict
 // padded plane (the 19-px REFLECT_101 frame supplies the border), row pass to
 // uint16 (<= 255*257), column pass (sum + 2^15) >> 16, saturated.
 // ---------------------------------------------------------------------------
-struct BlurW { int w[7]; };
-struct TileDesc { short level, tx, ty, pad; };
-constexpr int kBlurTW = 64, kBlurTH = 32;
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                               PyrGeom G, const TileDesc *__restrict__ tiles, BlurW W)
@@ -674,7 +671,6 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 // spread over the 64 lanes and reduced with shuffles.  Descriptor: test t = 64*j+lane,
 // so four 64-bit ballots are the 32 descriptor bytes (LSB-first) directly.
 // ---------------------------------------------------------------------------
-struct DiscTab { signed char u[768], v[768]; };  // 749 used
 
 __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restrict__ pyr,
                                                          const uint8_t *__restrict__ blur, PyrGeom G,
@@ -765,48 +761,6 @@ __global__ void k_zero_status(int *status, int n)
 // host side
 // ===========================================================================
 using namespace orbhip;
-
-struct orbhip_extractor {
-    int nfeatures = 0;
-    double scaleFactor = 1.2;
-    int nlevels = 8, iniTh = 20, minTh = 7, device = 0;
-    float sf[ORBHIP_MAX_LEVELS], isf[ORBHIP_MAX_LEVELS], sig2[ORBHIP_MAX_LEVELS], isig2[ORBHIP_MAX_LEVELS];
-    int nfeat[ORBHIP_MAX_LEVELS];
-    int umax[kHalfPatch + 1];
-    BlurW blurw;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool profiling = false, have_times = false;
-    float times[6] = {0, 0, 0, 0, 0, 0};
-
-    // geometry (bound to an image size)
-    bool bound = false;
-    PyrGeom G;
-    std::vector<CellDesc> cells;
-    std::vector<TileDesc> tiles;
-    int octree_maxn = 512;
-    CellDesc *d_cells = nullptr;
-    TileDesc *d_tiles = nullptr;
-    short *d_tabs = nullptr;
-    DiscTab *d_disc = nullptr;
-    int *d_pattern = nullptr;
-
-    // per-batch-capacity buffers
-    int batch_cap = 0;
-    int last_batch = 0;
-    uint8_t *d_pyr = nullptr, *d_blur = nullptr;
-    int *d_cell_cnt = nullptr;
-    uint32_t *d_cell_kp = nullptr;
-    uint32_t *d_keys = nullptr;
-    unsigned short *d_knode = nullptr;
-    uint32_t *d_sel = nullptr;
-    int *d_sel_cnt = nullptr;
-    int *d_status = nullptr;
-    // staging for the host-pointer API
-    uint8_t *d_img = nullptr; size_t d_img_bytes = 0;
-    orbhip_keypoint *d_okp = nullptr; uint8_t *d_odesc = nullptr; int *d_on = nullptr;
-    int out_cap = 0, out_batch = 0;
-};
 
 static int cv_round(double v) { return (int)lrint(v); }
 

@@ -1,0 +1,55 @@
+// Internal (non-ABI) definitions shared by the extractor and matcher translation units.
+#pragma once
+#include "orbhip_common.h"
+
+#include <vector>
+
+namespace orbhip {
+struct BlurW { int w[7]; };
+struct TileDesc { short level, tx, ty, pad; };
+constexpr int kBlurTW = 64, kBlurTH = 32;
+struct DiscTab { signed char u[768], v[768]; };  // 749 used
+}  // namespace orbhip
+
+struct orbhip_extractor {
+    int nfeatures = 0;
+    double scaleFactor = 1.2;
+    int nlevels = 8, iniTh = 20, minTh = 7, device = 0;
+    float sf[ORBHIP_MAX_LEVELS], isf[ORBHIP_MAX_LEVELS], sig2[ORBHIP_MAX_LEVELS], isig2[ORBHIP_MAX_LEVELS];
+    int nfeat[ORBHIP_MAX_LEVELS];
+    int umax[orbhip::kHalfPatch + 1];
+    orbhip::BlurW blurw;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool profiling = false, have_times = false;
+    float times[6] = {0, 0, 0, 0, 0, 0};
+
+    // geometry (bound to an image size)
+    bool bound = false;
+    orbhip::PyrGeom G;
+    std::vector<orbhip::CellDesc> cells;
+    std::vector<orbhip::TileDesc> tiles;
+    int octree_maxn = 512;
+    orbhip::CellDesc *d_cells = nullptr;
+    orbhip::TileDesc *d_tiles = nullptr;
+    short *d_tabs = nullptr;
+    orbhip::DiscTab *d_disc = nullptr;
+    int *d_pattern = nullptr;
+
+    // per-batch-capacity buffers
+    int batch_cap = 0;
+    int last_batch = 0;
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+    int *d_cell_cnt = nullptr;
+    uint32_t *d_cell_kp = nullptr;
+    uint32_t *d_keys = nullptr;
+    unsigned short *d_knode = nullptr;
+    uint32_t *d_sel = nullptr;
+    int *d_sel_cnt = nullptr;
+    int *d_status = nullptr;
+    // staging for the host-pointer API
+    uint8_t *d_img = nullptr; size_t d_img_bytes = 0;
+    orbhip_keypoint *d_okp = nullptr; uint8_t *d_odesc = nullptr; int *d_on = nullptr;
+    int out_cap = 0, out_batch = 0;
+};
+

@@ -1,1 +1,785 @@
-#include "orbhip_common.h"
+// MI355X (gfx950) descriptor matching behind the C ABI of include/orbhip.h.
+// Replaces ORBmatcher::SearchByProjection (x2), SearchForInitialization,
+// DescriptorDistance (src/ORBmatcher.cc) and Frame::ComputeStereoMatches
+// (src/Frame.cc:466-640).
+//
+// Structure: a fully parallel "window search" kernel (one wavefront per query:
+// Frame::GetFeaturesInArea membership test + 256-bit XOR/popcount Hamming
+// distance, candidates compacted with wave ballots and sorted by
+// (distance, reference visiting order)), followed by a single-wavefront
+// "resolve" kernel that replays the reference's order-dependent bookkeeping
+// (slots taken by earlier queries, match stealing, rotation histogram) over
+// state held in LDS.  Integer/bitwise path: no MFMA.
+#include "orbhip_internal.h"
+
+#include <algorithm>
+#include <climits>
+#include <new>
+#include <vector>
+
+namespace orbhip {
+
+constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;
+constexpr int GRID_ROWS = 48, GRID_COLS = 64;   // include/Frame.h:37-38
+constexpr int kResolveMax = 4096;               // LDS-resident state of the resolve kernel
+constexpr uint32_t kNoCell = 0xffffffffu;
+
+struct DevFrame {
+    int n;
+    const orbhip_keypoint *keys;
+    const uint8_t *desc;
+    const float *u_right;  // nullable
+    float min_x, min_y, inv_w, inv_h;
+};
+
+__device__ __forceinline__ int hamming256(const uint32_t *a, const uint32_t *b)
+{
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d += __popc(a[i] ^ b[i]);
+    return d;
+}
+
+__device__ __forceinline__ int wave_reduce_add_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// Visiting order of Frame::GetFeaturesInArea (cell-major ix outer / iy inner, insertion
+// order inside a cell; Frame.cc:350-358) as a sortable key: (posX*48+posY) << 20 | index.
+// Keypoints that PosInGrid rejects (Frame.cc:382-392) are never candidates.
+__global__ void k_grid_order(DevFrame F, uint32_t *__restrict__ ord)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= F.n) return;
+    const orbhip_keypoint kp = F.keys[j];
+    int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.min_x), F.inv_w));
+    int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, F.min_y), F.inv_h));
+    bool in = !(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS);
+    ord[j] = in ? (((uint32_t)(px * GRID_ROWS + py) << 20) | (uint32_t)j) : kNoCell;
+}
+
+// One wavefront per query.  Output: cand[q*stride + i] = dist << 32 | order key, sorted
+// ascending when the query has <= 64 candidates (cnt[q] > 0), unsorted otherwise (cnt[q] < 0,
+// magnitude = count).
+__global__ __launch_bounds__(256) void k_window_search(DevFrame F, const uint32_t *__restrict__ ord,
+                                                       const orbhip_query *__restrict__ q,
+                                                       const uint8_t *__restrict__ qdesc, int nq,
+                                                       unsigned long long *__restrict__ cand,
+                                                       int *__restrict__ cnt, int stride, int use_ur)
+{
+    __shared__ unsigned long long stage[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int qi = blockIdx.x * 4 + wv;
+    if (qi >= nq) return;
+    const orbhip_query Q = q[qi];
+    if (!Q.valid) { if (lane == 0) cnt[qi] = 0; return; }
+    const float x = Q.u, y = Q.v, r = Q.radius;
+    // Frame.cc:332-346
+    const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, F.min_x), r), F.inv_w)));
+    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, F.min_x), r), F.inv_w)));
+    const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, F.min_y), r), F.inv_h)));
+    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, F.min_y), r), F.inv_h)));
+    if (nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0) {
+        if (lane == 0) cnt[qi] = 0;
+        return;
+    }
+    const bool bCheckLevels = (Q.min_level > 0) || (Q.max_level >= 0);
+    uint32_t qd[8];
+    const uint32_t *qp = reinterpret_cast<const uint32_t *>(qdesc + (size_t)qi * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qd[i] = qp[i];
+    unsigned long long *out = cand + (size_t)qi * stride;
+    int total = 0;
+    for (int j0 = 0; j0 < F.n; j0 += 64) {
+        const int j = j0 + lane;
+        bool ok = false;
+        unsigned long long key = 0;
+        if (j < F.n) {
+            const uint32_t o = ord[j];
+            if (o != kNoCell) {
+                const int cell = (int)(o >> 20);
+                const int px = cell / GRID_ROWS, py = cell - px * GRID_ROWS;
+                const orbhip_keypoint kp = F.keys[j];
+                ok = px >= nMinCellX && px <= nMaxCellX && py >= nMinCellY && py <= nMaxCellY;
+                if (bCheckLevels) {
+                    if (kp.octave < Q.min_level) ok = false;
+                    if (Q.max_level >= 0 && kp.octave > Q.max_level) ok = false;
+                }
+                ok = ok && fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r;
+                if (ok && use_ur && F.u_right) {
+                    const float ur = F.u_right[j];
+                    if (ur > 0 && fabsf(__fsub_rn(Q.ur, ur)) > r) ok = false;
+                }
+                if (ok) {
+                    const uint32_t *tp = reinterpret_cast<const uint32_t *>(F.desc + (size_t)j * 32);
+                    uint32_t td[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) td[i] = tp[i];
+                    key = ((unsigned long long)hamming256(qd, td) << 32) | o;
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(ok);
+        if (ok) {
+            const int pos = total + __popcll(bal & ((1ull << lane) - 1ull));
+            out[pos] = key;
+            if (pos < 64) stage[wv][pos] = key;
+        }
+        total += __popcll(bal);
+    }
+    if (total > 0 && total <= 64) {
+        // wave bitonic sort of up to 64 keys (pad with ~0)
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long v = lane < total ? stage[wv][lane] : ~0ull;
+        for (int k = 2; k <= 64; k <<= 1)
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                unsigned long long o = __shfl_xor(v, jj, 64);
+                const bool up = ((lane & k) == 0);
+                const bool lower = ((lane & jj) == 0);
+                const unsigned long long mn = o < v ? o : v, mx = o < v ? v : o;
+                v = (lower == up) ? mn : mx;
+            }
+        if (lane < total) out[lane] = v;
+        if (lane == 0) cnt[qi] = total;
+    } else if (lane == 0) {
+        cnt[qi] = -total;
+    }
+}
+
+// ---- resolve ---------------------------------------------------------------------------
+// mode 0: SearchByProjection(Frame,Frame)  ORBmatcher.cc:1397-1467
+// mode 1: SearchByProjection(Frame,points) ORBmatcher.cc:76-125
+// mode 2: SearchForInitialization          ORBmatcher.cc:432-511
+struct ResolveShared {
+    unsigned short block[kResolveMax];   // mode 0/1: slot taken (0/1); mode 2: vMatchedDistance (0xffff = INT_MAX)
+    int assign[kResolveMax];             // mode 0/1: assign[]; mode 2: vnMatches21
+    int m12[kResolveMax];                // mode 2: vnMatches12
+    unsigned char evbin[kResolveMax];    // rotation-histogram bin of the event of query i (0xff none)
+    unsigned short evidx[kResolveMax];   // mode 0: bestIdx2 pushed into rotHist
+    int hist[HISTO_LENGTH];
+};
+
+__device__ __forceinline__ int rot_bin(float a1, float a2)
+{
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = __fsub_rn(a1, a2);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, factor));
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// First / second usable candidate of a query.  `usable(idx, dist)` is evaluated by every lane.
+template <class Usable>
+__device__ __forceinline__ void pick2(const unsigned long long *list, int c, int lane, Usable usable,
+                                      unsigned long long &k1, unsigned long long &k2)
+{
+    k1 = ~0ull; k2 = ~0ull;
+    if (c > 0) {  // sorted, <= 64
+        unsigned long long v = lane < c ? list[lane] : ~0ull;
+        bool u = lane < c && usable((int)(v & 0xfffffu), (int)(v >> 32));
+        unsigned long long bal = __ballot(u);
+        if (bal) {
+            int l1 = __ffsll((long long)bal) - 1;
+            k1 = __shfl(v, l1, 64);
+            bal &= bal - 1;
+            if (bal) { int l2 = __ffsll((long long)bal) - 1; k2 = __shfl(v, l2, 64); }
+        }
+    } else if (c < 0) {  // unsorted: two masked min-reductions
+        c = -c;
+        unsigned long long m1 = ~0ull;
+        for (int i = lane; i < c; i += 64) {
+            unsigned long long v = list[i];
+            if (usable((int)(v & 0xfffffu), (int)(v >> 32))) m1 = v < m1 ? v : m1;
+        }
+        k1 = wave_min_u64(m1);
+        unsigned long long m2 = ~0ull;
+        for (int i = lane; i < c; i += 64) {
+            unsigned long long v = list[i];
+            if (v != k1 && usable((int)(v & 0xfffffu), (int)(v >> 32))) m2 = v < m2 ? v : m2;
+        }
+        k2 = wave_min_u64(m2);
+    }
+}
+
+__device__ __forceinline__ void three_maxima(const int *h, int &ind1, int &ind2, int &ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; ++i) {
+        const int s = h[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+    else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+}
+
+__global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbhip_keypoint *__restrict__ qkeys,
+                                                const orbhip_query *__restrict__ q, int nq,
+                                                const unsigned long long *__restrict__ cand,
+                                                const int *__restrict__ cnt, int stride,
+                                                const uint8_t *__restrict__ taken_in, float nnratio,
+                                                int check_ori, int *__restrict__ out, int *__restrict__ out_n)
+{
+    __shared__ ResolveShared S;
+    const int lane = threadIdx.x;
+    const int n = F.n;
+    for (int i = lane; i < n; i += 64) {
+        S.block[i] = (mode == 2) ? 0xffff : (unsigned short)(taken_in ? taken_in[i] != 0 : 0);
+        S.assign[i] = -1;
+    }
+    for (int i = lane; i < nq; i += 64) { S.evbin[i] = 0xff; if (mode == 2) S.m12[i] = -1; }
+    if (lane < HISTO_LENGTH) S.hist[lane] = 0;
+    __syncthreads();
+    int nmatches = 0;
+    for (int i = 0; i < nq; ++i) {
+        const int c = cnt[i];
+        if (c == 0) continue;
+        const unsigned long long *list = cand + (size_t)i * stride;
+        unsigned long long k1, k2;
+        if (mode == 2) pick2(list, c, lane, [&](int idx, int dist) { return !((int)S.block[idx] <= dist); }, k1, k2);
+        else pick2(list, c, lane, [&](int idx, int) { return S.block[idx] == 0; }, k1, k2);
+        if (k1 == ~0ull) continue;
+        const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xfffffu);
+        if (mode == 0) {
+            if (bestDist <= TH_HIGH) {
+                if (lane == 0) {
+                    S.assign[bestIdx] = i;
+                    S.block[bestIdx] = (unsigned short)(q[i].observed != 0);
+                    if (check_ori) {
+                        int bin = rot_bin(q[i].angle, F.keys[bestIdx].angle);
+                        S.hist[bin]++;
+                        S.evbin[i] = (unsigned char)bin;
+                        S.evidx[i] = (unsigned short)bestIdx;
+                    }
+                }
+                nmatches++;
+            }
+        } else if (mode == 1) {
+            if (bestDist <= TH_HIGH) {
+                const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
+                const int bestLevel = F.keys[bestIdx].octave;
+                const int bestLevel2 = k2 == ~0ull ? -1 : F.keys[(int)(k2 & 0xfffffu)].octave;
+                if (!(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2))) {
+                    if (lane == 0) {
+                        S.assign[bestIdx] = i;
+                        S.block[bestIdx] = (unsigned short)(q[i].observed != 0);
+                    }
+                    nmatches++;
+                }
+            }
+        } else {
+            if (bestDist <= TH_LOW) {
+                // bestDist < (float)bestDist2 * mfNNratio with bestDist2 = INT_MAX when absent
+                const float d2 = k2 == ~0ull ? (float)INT_MAX : (float)(int)(k2 >> 32);
+                if ((float)bestDist < __fmul_rn(d2, nnratio)) {
+                    const int prev = S.assign[bestIdx];  // vnMatches21
+                    if (prev >= 0) nmatches--;
+                    if (lane == 0) {
+                        if (prev >= 0) S.m12[prev] = -1;
+                        S.m12[i] = bestIdx;
+                        S.assign[bestIdx] = i;
+                        S.block[bestIdx] = (unsigned short)bestDist;
+                        if (check_ori) {
+                            int bin = rot_bin(qkeys[i].angle, F.keys[bestIdx].angle);
+                            S.hist[bin]++;
+                            S.evbin[i] = (unsigned char)bin;
+                        }
+                    }
+                    nmatches++;
+                }
+            }
+        }
+        __syncthreads();  // single wave: orders lane 0's LDS writes before the next query reads them
+    }
+    __syncthreads();
+    if (check_ori && mode != 1) {
+        int ind1, ind2, ind3;
+        three_maxima(S.hist, ind1, ind2, ind3);
+        // events are independent of each other: every one in a losing bin clears its slot
+        int dec = 0;
+        if (mode == 0) {
+            for (int i = lane; i < nq; i += 64) {
+                int b = S.evbin[i];
+                if (b != 0xff && b != ind1 && b != ind2 && b != ind3) { S.assign[S.evidx[i]] = -1; dec++; }
+            }
+        } else {
+            for (int i = lane; i < nq; i += 64) {
+                int b = S.evbin[i];
+                if (b != 0xff && b != ind1 && b != ind2 && b != ind3 && S.m12[i] >= 0) { S.m12[i] = -1; dec++; }
+            }
+        }
+        nmatches -= wave_reduce_add_i(dec);
+    }
+    __syncthreads();
+    if (mode == 2) for (int i = lane; i < nq; i += 64) out[i] = S.m12[i];
+    else for (int i = lane; i < n; i += 64) out[i] = S.assign[i];
+    if (lane == 0) *out_n = nmatches;
+}
+
+// ---- DescriptorDistance, batched (ORBmatcher.cc:1647-1663) --------------------------------
+__global__ void k_distance_matrix(const uint8_t *__restrict__ a, int na, const uint8_t *__restrict__ b, int nb,
+                                  int *__restrict__ dist)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= nb || i >= na) return;
+    const uint32_t *pa = reinterpret_cast<const uint32_t *>(a + (size_t)i * 32);
+    const uint32_t *pb = reinterpret_cast<const uint32_t *>(b + (size_t)j * 32);
+    int d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d += __popc(pa[k] ^ pb[k]);
+    dist[(size_t)i * nb + j] = d;
+}
+
+// ---- Frame::ComputeStereoMatches (Frame.cc:466-640) -----------------------------------------
+struct StereoGeom {
+    int nlevels, nrows;
+    const uint8_t *left[ORBHIP_MAX_LEVELS], *right[ORBHIP_MAX_LEVELS];
+    int pitch_l[ORBHIP_MAX_LEVELS], pitch_r[ORBHIP_MAX_LEVELS], cols_r[ORBHIP_MAX_LEVELS];
+    float sf[ORBHIP_MAX_LEVELS], isf[ORBHIP_MAX_LEVELS];
+    float mbf, mb;
+};
+
+// row band of every right keypoint (Frame.cc:483-493)
+__global__ void k_stereo_rows(const orbhip_keypoint *__restrict__ kr, int nr, StereoGeom G, int2 *__restrict__ band)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nr) return;
+    const float kpY = kr[i].y;
+    const float r = __fmul_rn(2.0f, G.sf[kr[i].octave]);
+    band[i] = make_int2((int)floorf(__fsub_rn(kpY, r)), (int)ceilf(__fadd_rn(kpY, r)));
+}
+
+__global__ __launch_bounds__(256) void k_stereo_match(const orbhip_keypoint *__restrict__ kl,
+                                                      const uint8_t *__restrict__ dl, int nl,
+                                                      const orbhip_keypoint *__restrict__ kr,
+                                                      const uint8_t *__restrict__ dr, int nr,
+                                                      const int2 *__restrict__ band, StereoGeom G,
+                                                      float *__restrict__ uRight, float *__restrict__ depth,
+                                                      int *__restrict__ sad)
+{
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= nl) return;
+    if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; sad[iL] = -1; }
+    const orbhip_keypoint kpL = kl[iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const int row = (int)vL;
+    if (row < 0 || row >= G.nrows) return;
+    const float minZ = G.mb, minD = 0.f;
+    const float maxD = __fdiv_rn(G.mbf, minZ);
+    const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
+    if (maxU < 0) return;
+    uint32_t qd[8];
+    const uint32_t *qp = reinterpret_cast<const uint32_t *>(dl + (size_t)iL * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qd[i] = qp[i];
+    // best right keypoint on this row: smallest (dist, iR) with dist < TH_HIGH (:522-549)
+    unsigned long long best = ((unsigned long long)TH_HIGH << 32);
+    for (int j0 = 0; j0 < nr; j0 += 64) {
+        const int iR = j0 + lane;
+        if (iR < nr) {
+            const int2 bd = band[iR];
+            const orbhip_keypoint kpR = kr[iR];
+            if (row >= bd.x && row <= bd.y && !(kpR.octave < levelL - 1 || kpR.octave > levelL + 1) &&
+                kpR.x >= minU && kpR.x <= maxU) {
+                const uint32_t *tp = reinterpret_cast<const uint32_t *>(dr + (size_t)iR * 32);
+                uint32_t td[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) td[i] = tp[i];
+                unsigned long long key = ((unsigned long long)hamming256(qd, td) << 32) | (uint32_t)iR;
+                best = key < best ? key : best;
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    const int bestDist = (int)(best >> 32);
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    if (!(bestDist < thOrbDist)) return;
+    const int bestIdxR = (int)(best & 0xffffffffu);
+    // sub-pixel refinement by 11x11 SAD over 11 shifts at the keypoint's level (:555-592)
+    const float uR0 = kr[bestIdxR].x;
+    const float scaleFactor = G.isf[levelL];
+    const float scaleduL = roundf(__fmul_rn(kpL.x, scaleFactor));
+    const float scaledvL = roundf(__fmul_rn(kpL.y, scaleFactor));
+    const float scaleduR0 = roundf(__fmul_rn(uR0, scaleFactor));
+    const int w = 5, L = 5;
+    const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)L), (float)w);
+    const float endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, (float)L), (float)w), 1.0f);
+    if (iniu < 0 || endu >= (float)G.cols_r[levelL]) return;
+    const uint8_t *imL = G.left[levelL], *imR = G.right[levelL];
+    const int stL = G.pitch_l[levelL], stR = G.pitch_r[levelL];
+    const int cu = (int)scaleduL, cv = (int)scaledvL, cr = (int)scaleduR0;
+    const int cL = imL[(ptrdiff_t)cv * stL + cu];
+    // each lane owns up to 2 of the 121 patch pixels
+    int pl[2], dyv[2], dxv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int p = lane + 64 * t;
+        dyv[t] = p / 11 - w; dxv[t] = p % 11 - w;
+        pl[t] = p < 121 ? (int)imL[(ptrdiff_t)(cv + dyv[t]) * stL + cu + dxv[t]] - cL : 0;
+    }
+    int dists[11];
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+        const int incR = s - L;
+        const int cR = imR[(ptrdiff_t)cv * stR + cr + incR];
+        int acc = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int p = lane + 64 * t;
+            if (p < 121) {
+                int b = (int)imR[(ptrdiff_t)(cv + dyv[t]) * stR + cr + incR + dxv[t]] - cR;
+                acc += abs(pl[t] - b);
+            }
+        }
+        dists[s] = wave_reduce_add_i(acc);
+    }
+    int bestD = INT_MAX, bestincR = 0;
+#pragma unroll
+    for (int s = 0; s < 11; ++s) if (dists[s] < bestD) { bestD = dists[s]; bestincR = s - L; }
+    if (bestincR == -L || bestincR == L) return;
+    float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+    for (int s = 1; s < 10; ++s) if (s == L + bestincR) { dist1 = (float)dists[s - 1]; dist2 = (float)dists[s]; dist3 = (float)dists[s + 1]; }
+    const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3),
+                                   __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));
+    if (deltaR < -1 || deltaR > 1) return;
+    float bestuR = __fmul_rn(G.sf[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestincR), deltaR));
+    float disparity = __fsub_rn(uL, bestuR);
+    if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) {
+            disparity = 0.01f;                              // float(0.01)
+            bestuR = (float)((double)uL - 0.01);            // float - double literal
+        }
+        if (lane == 0) {
+            depth[iL] = __fdiv_rn(G.mbf, disparity);
+            uRight[iL] = bestuR;
+            sad[iL] = bestD;
+        }
+    }
+}
+
+// median-based outlier cull (:626-639): thDist = 1.5f*1.4f*median of the SAD list sorted by
+// (dist, iL); entries with dist >= thDist are removed.
+__global__ __launch_bounds__(256) void k_stereo_cull(int nl, const int *__restrict__ sad, float *__restrict__ uRight,
+                                                     float *__restrict__ depth, int *__restrict__ out_n)
+{
+    __shared__ int s_nd, s_med, s_cnt;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_nd = 0; s_med = 0; s_cnt = 0; }
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < nl; i += 256) local += sad[i] >= 0;
+    atomicAdd(&s_nd, local);
+    __syncthreads();
+    const int nd = s_nd;
+    if (nd == 0) { if (tid == 0) *out_n = 0; return; }
+    const int target = nd / 2;
+    for (int i = tid; i < nl; i += 256) {
+        const int d = sad[i];
+        if (d < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < nl; ++j) {
+            const int dj = sad[j];
+            rank += (dj >= 0) && (dj < d || (dj == d && j < i));
+        }
+        if (rank == target) s_med = d;
+    }
+    __syncthreads();
+    const float median = (float)s_med;
+    const float thDist = __fmul_rn(1.5f * 1.4f, median);
+    int kept = 0;
+    for (int i = tid; i < nl; i += 256) {
+        const int d = sad[i];
+        if (d < 0) continue;
+        if (!((float)d < thDist)) { uRight[i] = -1; depth[i] = -1; }
+        else kept++;
+    }
+    atomicAdd(&s_cnt, kept);
+    __syncthreads();
+    if (tid == 0) *out_n = s_cnt;
+}
+
+}  // namespace orbhip
+
+// =============================================================================================
+using namespace orbhip;
+
+struct orbhip_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // grow-only device scratch
+    void *buf[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+static int scratch(orbhip_matcher *m, int slot, size_t bytes, void **out)
+{
+    if (bytes < 256) bytes = 256;
+    if (bytes > m->cap[slot]) {
+        ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+        hipFree(m->buf[slot]);
+        m->buf[slot] = nullptr; m->cap[slot] = 0;
+        ORBHIP_HIP_CHECK(hipMalloc(&m->buf[slot], bytes));
+        m->cap[slot] = bytes;
+    }
+    *out = m->buf[slot];
+    return ORBHIP_OK;
+}
+
+enum { S_KEYS = 0, S_DESC, S_UR, S_ORD, S_Q, S_QDESC, S_CAND, S_CNT, S_TAKEN, S_OUT, S_QKEYS, S_MISC };
+
+static int upload_frame(orbhip_matcher *m, const orbhip_frame_view *f, DevFrame *D, uint32_t **d_ord)
+{
+    void *p;
+    int rc;
+    const size_t n = (size_t)std::max(f->n, 1);
+    if ((rc = scratch(m, S_KEYS, n * sizeof(orbhip_keypoint), &p))) return rc;
+    D->keys = (const orbhip_keypoint *)p;
+    if ((rc = scratch(m, S_DESC, n * 32, &p))) return rc;
+    D->desc = (const uint8_t *)p;
+    D->u_right = nullptr;
+    if (f->u_right) { if ((rc = scratch(m, S_UR, n * sizeof(float), &p))) return rc; D->u_right = (const float *)p; }
+    if ((rc = scratch(m, S_ORD, n * sizeof(uint32_t), &p))) return rc;
+    *d_ord = (uint32_t *)p;
+    D->n = f->n; D->min_x = f->min_x; D->min_y = f->min_y; D->inv_w = f->grid_inv_w; D->inv_h = f->grid_inv_h;
+    if (f->n > 0) {
+        ORBHIP_HIP_CHECK(hipMemcpyAsync((void *)D->keys, f->keys, f->n * sizeof(orbhip_keypoint), hipMemcpyHostToDevice, m->stream));
+        ORBHIP_HIP_CHECK(hipMemcpyAsync((void *)D->desc, f->desc, (size_t)f->n * 32, hipMemcpyHostToDevice, m->stream));
+        if (f->u_right) ORBHIP_HIP_CHECK(hipMemcpyAsync((void *)D->u_right, f->u_right, f->n * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        hipLaunchKernelGGL(k_grid_order, dim3((f->n + 255) / 256), dim3(256), 0, m->stream, *D, *d_ord);
+    }
+    return ORBHIP_OK;
+}
+
+// shared driver of the three windowed searches
+static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *train, const orbhip_query *q,
+                      const uint8_t *qdesc, const orbhip_keypoint *qkeys, int nq, const uint8_t *taken,
+                      float nnratio, int check_ori, int32_t *out, int nout, int *nmatches)
+{
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    if (train->n > kResolveMax || nq > kResolveMax || train->n >= (1 << 20)) {
+        set_error("matcher: %d train / %d query keypoints exceed the LDS-resident limit %d", train->n, nq, kResolveMax);
+        return ORBHIP_E_CAPACITY;
+    }
+    for (int i = 0; i < nout; ++i) out[i] = -1;
+    *nmatches = 0;
+    if (nq == 0 || train->n == 0) return ORBHIP_OK;
+    DevFrame D;
+    uint32_t *d_ord;
+    int rc;
+    if ((rc = upload_frame(m, train, &D, &d_ord))) return rc;
+    void *p;
+    if ((rc = scratch(m, S_Q, (size_t)nq * sizeof(orbhip_query), &p))) return rc;
+    orbhip_query *d_q = (orbhip_query *)p;
+    if ((rc = scratch(m, S_QDESC, (size_t)nq * 32, &p))) return rc;
+    uint8_t *d_qdesc = (uint8_t *)p;
+    const int stride = (train->n + 1) & ~1;
+    if ((rc = scratch(m, S_CAND, (size_t)nq * stride * sizeof(unsigned long long), &p))) return rc;
+    unsigned long long *d_cand = (unsigned long long *)p;
+    if ((rc = scratch(m, S_CNT, (size_t)nq * sizeof(int), &p))) return rc;
+    int *d_cnt = (int *)p;
+    if ((rc = scratch(m, S_OUT, (size_t)(nout + 1) * sizeof(int), &p))) return rc;
+    int *d_out = (int *)p;
+    uint8_t *d_taken = nullptr;
+    if (taken) {
+        if ((rc = scratch(m, S_TAKEN, (size_t)train->n, &p))) return rc;
+        d_taken = (uint8_t *)p;
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(d_taken, taken, train->n, hipMemcpyHostToDevice, m->stream));
+    }
+    orbhip_keypoint *d_qkeys = nullptr;
+    if (qkeys) {
+        if ((rc = scratch(m, S_QKEYS, (size_t)nq * sizeof(orbhip_keypoint), &p))) return rc;
+        d_qkeys = (orbhip_keypoint *)p;
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(d_qkeys, qkeys, (size_t)nq * sizeof(orbhip_keypoint), hipMemcpyHostToDevice, m->stream));
+    }
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_q, q, (size_t)nq * sizeof(orbhip_query), hipMemcpyHostToDevice, m->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_qdesc, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_ord, d_q, d_qdesc, nq, d_cand,
+                       d_cnt, stride, mode != 2);
+    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, m->stream, mode, D, d_qkeys, d_q, nq, d_cand, d_cnt, stride,
+                       d_taken, nnratio, check_ori, d_out, d_out + nout);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    std::vector<int> host(nout + 1);
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(host.data(), d_out, (size_t)(nout + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    memcpy(out, host.data(), (size_t)nout * sizeof(int));
+    *nmatches = host[nout];
+    return ORBHIP_OK;
+}
+
+extern "C" {
+
+int orbhip_matcher_create(int device, orbhip_matcher **out)
+{
+    if (!out) return ORBHIP_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_error("no HIP device %d (found %d)", device, ndev);
+        return ORBHIP_E_NODEVICE;
+    }
+    orbhip_matcher *m = new (std::nothrow) orbhip_matcher();
+    if (!m) return ORBHIP_E_ARG;
+    m->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipSetDevice/hipStreamCreate failed");
+        delete m;
+        return ORBHIP_E_HIP;
+    }
+    *out = m;
+    return ORBHIP_OK;
+}
+
+void orbhip_matcher_destroy(orbhip_matcher *m)
+{
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    for (int i = 0; i < 12; ++i) hipFree(m->buf[i]);
+    if (m->stream) hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int orbhip_descriptor_distance(orbhip_matcher *m, const uint8_t *a, int na, const uint8_t *b, int nb, int32_t *dist)
+{
+    if (!m || !a || !b || !dist || na < 0 || nb < 0) return ORBHIP_E_ARG;
+    if (na == 0 || nb == 0) return ORBHIP_OK;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    void *pa, *pb, *pd;
+    int rc;
+    if ((rc = scratch(m, S_DESC, (size_t)na * 32, &pa))) return rc;
+    if ((rc = scratch(m, S_QDESC, (size_t)nb * 32, &pb))) return rc;
+    if ((rc = scratch(m, S_CAND, (size_t)na * nb * sizeof(int), &pd))) return rc;
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(pa, a, (size_t)na * 32, hipMemcpyHostToDevice, m->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(pb, b, (size_t)nb * 32, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_distance_matrix, dim3((nb + 255) / 256, na), dim3(256), 0, m->stream, (const uint8_t *)pa, na,
+                       (const uint8_t *)pb, nb, (int *)pd);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(dist, pd, (size_t)na * nb * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBHIP_OK;
+}
+
+int orbhip_search_for_initialization(orbhip_matcher *m, const orbhip_frame_view *f1, const orbhip_frame_view *f2,
+                                     float *prev_matched_xy, int32_t *matches12, int window_size, float nnratio,
+                                     int check_ori, int *nmatches)
+{
+    if (!m || !f1 || !f2 || !prev_matched_xy || !matches12 || !nmatches) return ORBHIP_E_ARG;
+    const int n1 = f1->n;
+    // queries: level-0 keypoints of F1 searched around vbPrevMatched (ORBmatcher.cc:418-425)
+    std::vector<orbhip_query> q((size_t)std::max(n1, 1));
+    for (int i = 0; i < n1; ++i) {
+        orbhip_query &Q = q[i];
+        memset(&Q, 0, sizeof(Q));
+        const int level1 = f1->keys[i].octave;
+        Q.valid = level1 > 0 ? 0 : 1;
+        Q.u = prev_matched_xy[2 * i]; Q.v = prev_matched_xy[2 * i + 1];
+        Q.radius = (float)window_size;
+        Q.min_level = level1; Q.max_level = level1;
+        Q.angle = f1->keys[i].angle;
+    }
+    int rc = run_search(m, 2, f2, q.data(), f1->desc, f1->keys, n1, nullptr, nnratio, check_ori, matches12, n1, nmatches);
+    if (rc) return rc;
+    for (int i = 0; i < n1; ++i)  // :515-517
+        if (matches12[i] >= 0) {
+            prev_matched_xy[2 * i] = f2->keys[matches12[i]].x;
+            prev_matched_xy[2 * i + 1] = f2->keys[matches12[i]].y;
+        }
+    return ORBHIP_OK;
+}
+
+int orbhip_search_by_projection_frame(orbhip_matcher *m, const orbhip_frame_view *cur, const orbhip_query *q,
+                                      const uint8_t *qdesc, int nq, const uint8_t *taken, int32_t *assign,
+                                      int check_ori, int *nmatches)
+{
+    if (!m || !cur || (nq > 0 && (!q || !qdesc)) || !assign || !nmatches || nq < 0) return ORBHIP_E_ARG;
+    return run_search(m, 0, cur, q, qdesc, nullptr, nq, taken, 0.f, check_ori, assign, cur->n, nmatches);
+}
+
+int orbhip_search_by_projection_points(orbhip_matcher *m, const orbhip_frame_view *f, const orbhip_query *q,
+                                       const uint8_t *qdesc, int nq, const uint8_t *taken, int32_t *assign,
+                                       float nnratio, int *nmatches)
+{
+    if (!m || !f || (nq > 0 && (!q || !qdesc)) || !assign || !nmatches || nq < 0) return ORBHIP_E_ARG;
+    return run_search(m, 1, f, q, qdesc, nullptr, nq, taken, nnratio, 0, assign, f->n, nmatches);
+}
+
+int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int frame_l, orbhip_extractor *right,
+                                  int frame_r, const orbhip_keypoint *keys_l, const uint8_t *desc_l, int nl,
+                                  const orbhip_keypoint *keys_r, const uint8_t *desc_r, int nr, float mbf, float mb,
+                                  float *u_right, float *depth, int *nmatches)
+{
+    if (!m || !left || !right || !u_right || !depth || !nmatches || nl < 0 || nr < 0) return ORBHIP_E_ARG;
+    if (!left->bound || !right->bound || frame_l < 0 || frame_l >= left->last_batch || frame_r < 0 ||
+        frame_r >= right->last_batch || left->device != m->device || right->device != m->device ||
+        left->nlevels != right->nlevels) {
+        set_error("stereo: extractor handles do not hold matching pyramids on device %d", m->device);
+        return ORBHIP_E_ARG;
+    }
+    for (int i = 0; i < nl; ++i) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+    *nmatches = 0;
+    if (nl == 0 || nr == 0) return ORBHIP_OK;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    // the pyramids were produced on the extractors' streams
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(left->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(right->stream));
+    StereoGeom G;
+    memset(&G, 0, sizeof(G));
+    G.nlevels = left->nlevels; G.nrows = left->G.lv[0].h; G.mbf = mbf; G.mb = mb;
+    for (int l = 0; l < G.nlevels; ++l) {
+        const LevelGeom &A = left->G.lv[l], &B = right->G.lv[l];
+        G.left[l] = left->d_pyr + (size_t)frame_l * left->G.frame_bytes + A.plane_off + (size_t)kEdge * A.pitch + kPadL;
+        G.right[l] = right->d_pyr + (size_t)frame_r * right->G.frame_bytes + B.plane_off + (size_t)kEdge * B.pitch + kPadL;
+        G.pitch_l[l] = A.pitch; G.pitch_r[l] = B.pitch; G.cols_r[l] = B.w;
+        G.sf[l] = left->sf[l]; G.isf[l] = left->isf[l];
+    }
+    void *p;
+    int rc;
+    if ((rc = scratch(m, S_KEYS, (size_t)nl * sizeof(orbhip_keypoint), &p))) return rc;
+    orbhip_keypoint *d_kl = (orbhip_keypoint *)p;
+    if ((rc = scratch(m, S_DESC, (size_t)nl * 32, &p))) return rc;
+    uint8_t *d_dl = (uint8_t *)p;
+    if ((rc = scratch(m, S_QKEYS, (size_t)nr * sizeof(orbhip_keypoint), &p))) return rc;
+    orbhip_keypoint *d_kr = (orbhip_keypoint *)p;
+    if ((rc = scratch(m, S_QDESC, (size_t)nr * 32, &p))) return rc;
+    uint8_t *d_dr = (uint8_t *)p;
+    if ((rc = scratch(m, S_ORD, (size_t)nr * sizeof(int2), &p))) return rc;
+    int2 *d_band = (int2 *)p;
+    if ((rc = scratch(m, S_OUT, (size_t)nl * 2 * sizeof(float), &p))) return rc;
+    float *d_ur = (float *)p, *d_depth = d_ur + nl;
+    if ((rc = scratch(m, S_CNT, (size_t)(nl + 1) * sizeof(int), &p))) return rc;
+    int *d_sad = (int *)p, *d_n = d_sad + nl;
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_kl, keys_l, (size_t)nl * sizeof(orbhip_keypoint), hipMemcpyHostToDevice, m->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_dl, desc_l, (size_t)nl * 32, hipMemcpyHostToDevice, m->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_kr, keys_r, (size_t)nr * sizeof(orbhip_keypoint), hipMemcpyHostToDevice, m->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_dr, desc_r, (size_t)nr * 32, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_stereo_rows, dim3((nr + 255) / 256), dim3(256), 0, m->stream, d_kr, nr, G, d_band);
+    hipLaunchKernelGGL(k_stereo_match, dim3((nl + 3) / 4), dim3(256), 0, m->stream, d_kl, d_dl, nl, d_kr, d_dr, nr, d_band,
+                       G, d_ur, d_depth, d_sad);
+    hipLaunchKernelGGL(k_stereo_cull, dim3(1), dim3(256), 0, m->stream, nl, d_sad, d_ur, d_depth, d_n);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(u_right, d_ur, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(depth, d_depth, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(nmatches, d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBHIP_OK;
+}
+
+}  // extern "C"

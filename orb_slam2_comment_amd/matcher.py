@@ -1,0 +1,183 @@
+"""Host-side mirror of class ORBmatcher (include/ORBmatcher.h:37-103) and of
+Frame::ComputeStereoMatches (src/Frame.cc:466-640) over the C ABI.
+
+`FrameView` carries the handful of Frame fields the matchers read (mvKeysUn,
+mDescriptors, mvuRight, image bounds, 64x48 grid scale, mvScaleFactors).  The
+projection that precedes the two SearchByProjection searches
+(src/ORBmatcher.cc:1360-1390, src/Frame.cc:269-325) is done by the caller and
+arrives as `QUERY_DTYPE` records; `project_last_frame` / `project_map_points`
+below restate it for callers that hold plain arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import KP_DTYPE, QUERY_DTYPE, check, lib, ptr
+
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+FRAME_GRID_ROWS, FRAME_GRID_COLS = 48, 64
+
+
+class FrameView:
+    """Flat view of a Frame (include/Frame.h) for the matchers."""
+
+    def __init__(self, keys_un, descriptors, scale_factors, bounds, u_right=None):
+        self.keys = np.ascontiguousarray(keys_un, KP_DTYPE)
+        self.desc = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        self.scale_factors = np.ascontiguousarray(scale_factors, np.float32)
+        self.u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        self.bounds = tuple(np.float32(b) for b in bounds)  # mnMinX, mnMinY, mnMaxX, mnMaxY
+        # src/Frame.cc:101-102
+        self.grid_inv_w = np.float32(FRAME_GRID_COLS) / (self.bounds[2] - self.bounds[0])
+        self.grid_inv_h = np.float32(FRAME_GRID_ROWS) / (self.bounds[3] - self.bounds[1])
+        self.N = len(self.keys)
+
+    def c_view(self):
+        v = capi.FrameView()
+        v.n = self.N
+        v.keys, v.desc, v.u_right = ptr(self.keys), ptr(self.desc), ptr(self.u_right)
+        v.min_x, v.min_y, v.max_x, v.max_y = self.bounds
+        v.grid_inv_w, v.grid_inv_h = self.grid_inv_w, self.grid_inv_h
+        v.n_levels = len(self.scale_factors)
+        v.scale_factors = ptr(self.scale_factors)
+        return v
+
+
+class ORBmatcher:
+    TH_HIGH, TH_LOW, HISTO_LENGTH = TH_HIGH, TH_LOW, HISTO_LENGTH
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self._lib = lib()
+        h = C.c_void_p()
+        check(self._lib.orbhip_matcher_create(device, C.byref(h)), "orbhip_matcher_create")
+        self._h = h
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.orbhip_matcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- DescriptorDistance (src/ORBmatcher.cc:1647-1663), batched ------------
+    def DescriptorDistance(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+        out = np.zeros((len(a), len(b)), np.int32)
+        check(self._lib.orbhip_descriptor_distance(self._h, ptr(a), len(a), ptr(b), len(b), ptr(out)),
+              "orbhip_descriptor_distance")
+        return out
+
+    # -- SearchForInitialization (src/ORBmatcher.cc:405-520) -------------------
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10):
+        """Returns (nmatches, vnMatches12, updated vbPrevMatched)."""
+        pm = np.ascontiguousarray(vbPrevMatched, np.float32).reshape(-1, 2).copy()
+        m12 = np.full(max(F1.N, 1), -1, np.int32)
+        n = C.c_int()
+        v1, v2 = F1.c_view(), F2.c_view()
+        check(self._lib.orbhip_search_for_initialization(self._h, C.byref(v1), C.byref(v2), ptr(pm), ptr(m12),
+                                                         int(windowSize), self.mfNNratio,
+                                                         int(self.mbCheckOrientation), C.byref(n)),
+              "orbhip_search_for_initialization")
+        return n.value, m12[:F1.N].copy(), pm
+
+    # -- SearchByProjection(CurrentFrame, LastFrame, th, bMono) (:1328-1470) ---
+    def SearchByProjectionFrame(self, CurrentFrame, queries, query_desc, taken=None):
+        """queries: QUERY_DTYPE[nq] (already projected).  Returns (nmatches, assign[N])."""
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        qd = np.ascontiguousarray(query_desc, np.uint8).reshape(-1, 32)
+        tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+        out = np.full(max(CurrentFrame.N, 1), -1, np.int32)
+        n = C.c_int()
+        v = CurrentFrame.c_view()
+        check(self._lib.orbhip_search_by_projection_frame(self._h, C.byref(v), ptr(q), ptr(qd), len(q), ptr(tk),
+                                                          ptr(out), int(self.mbCheckOrientation), C.byref(n)),
+              "orbhip_search_by_projection_frame")
+        return n.value, out[:CurrentFrame.N].copy()
+
+    # -- SearchByProjection(F, vpMapPoints, th) (:45-129) ----------------------
+    def SearchByProjectionPoints(self, F, queries, query_desc, taken=None):
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        qd = np.ascontiguousarray(query_desc, np.uint8).reshape(-1, 32)
+        tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+        out = np.full(max(F.N, 1), -1, np.int32)
+        n = C.c_int()
+        v = F.c_view()
+        check(self._lib.orbhip_search_by_projection_points(self._h, C.byref(v), ptr(q), ptr(qd), len(q), ptr(tk),
+                                                           ptr(out), self.mfNNratio, C.byref(n)),
+              "orbhip_search_by_projection_points")
+        return n.value, out[:F.N].copy()
+
+    # -- Frame::ComputeStereoMatches (src/Frame.cc:466-640) --------------------
+    def ComputeStereoMatches(self, extractor_left, extractor_right, keys_l, desc_l, keys_r, desc_r, mbf, mb,
+                             frame_l=0, frame_r=0):
+        """Pyramids are those held by the two extractor handles after their last call.
+        Returns (nmatches, mvuRight, mvDepth)."""
+        kl = np.ascontiguousarray(keys_l, KP_DTYPE)
+        kr = np.ascontiguousarray(keys_r, KP_DTYPE)
+        dl = np.ascontiguousarray(desc_l, np.uint8)
+        dr = np.ascontiguousarray(desc_r, np.uint8)
+        ur = np.full(max(len(kl), 1), -1, np.float32)
+        dp = np.full(max(len(kl), 1), -1, np.float32)
+        n = C.c_int()
+        check(self._lib.orbhip_compute_stereo_matches(self._h, extractor_left._h, frame_l, extractor_right._h,
+                                                      frame_r, ptr(kl), ptr(dl), len(kl), ptr(kr), ptr(dr),
+                                                      len(kr), mbf, mb, ptr(ur), ptr(dp), C.byref(n)),
+              "orbhip_compute_stereo_matches")
+        return n.value, ur[:len(kl)].copy(), dp[:len(kl)].copy()
+
+
+def RadiusByViewingCos(viewCos):
+    """src/ORBmatcher.cc:131-137"""
+    return 2.5 if viewCos > 0.998 else 4.0
+
+
+def project_last_frame(Tcw, K, bounds, world_pts, last_octaves, last_angles, valid, observed, scale_factors,
+                       th, mbf=0.0, bForward=False, bBackward=False):
+    """Projection prologue of SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+    (src/ORBmatcher.cc:1360-1390) in float32, one operation at a time.
+    K = (fx, fy, cx, cy); Tcw 4x4; world_pts [n,3].  Returns QUERY_DTYPE[n]."""
+    f32 = np.float32
+    Tcw = np.asarray(Tcw, f32)
+    P = np.asarray(world_pts, f32)
+    fx, fy, cx, cy = (f32(v) for v in K)
+    n = len(P)
+    q = np.zeros(n, QUERY_DTYPE)
+    R, t = Tcw[:3, :3], Tcw[:3, 3]
+    for i in range(n):
+        if not valid[i]:
+            continue
+        xc = f32(f32(f32(R[0, 0] * P[i, 0]) + f32(R[0, 1] * P[i, 1])) + f32(R[0, 2] * P[i, 2])) + t[0]
+        yc = f32(f32(f32(R[1, 0] * P[i, 0]) + f32(R[1, 1] * P[i, 1])) + f32(R[1, 2] * P[i, 2])) + t[1]
+        zc = f32(f32(f32(R[2, 0] * P[i, 0]) + f32(R[2, 1] * P[i, 1])) + f32(R[2, 2] * P[i, 2])) + t[2]
+        if zc == 0:
+            continue
+        invzc = f32(1.0 / np.float64(zc))
+        if invzc < 0:
+            continue
+        u = f32(f32(f32(fx * xc) * invzc) + cx)
+        v = f32(f32(f32(fy * yc) * invzc) + cy)
+        if u < bounds[0] or u > bounds[2] or v < bounds[1] or v > bounds[3]:
+            continue
+        o = int(last_octaves[i])
+        q[i]["valid"] = 1
+        q[i]["u"], q[i]["v"] = u, v
+        q[i]["radius"] = f32(f32(th) * f32(scale_factors[o]))
+        if bForward:
+            q[i]["min_level"], q[i]["max_level"] = o, -1
+        elif bBackward:
+            q[i]["min_level"], q[i]["max_level"] = 0, o
+        else:
+            q[i]["min_level"], q[i]["max_level"] = o - 1, o + 1
+        q[i]["ur"] = f32(u - f32(f32(mbf) * invzc))
+        q[i]["level_aux"] = o
+        q[i]["angle"] = last_angles[i]
+        q[i]["observed"] = int(observed[i])
+    return q

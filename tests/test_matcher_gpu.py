@@ -1,0 +1,216 @@
+"""Parity of the HIP matchers against the oracle, through the C ABI.
+Stated tolerance (BASELINE north_star: "match sets within a stated tolerance"): match sets,
+assignment arrays and match counts must be IDENTICAL (integer Hamming distances, same visiting
+order); mvuRight / mvDepth must agree to 1e-6 relative (they are produced by the same float
+operation sequence, so in practice they are bit-identical)."""
+import numpy as np
+import pytest
+
+from helpers import frame_bounds, synth_frame, synth_stereo
+
+pytestmark = pytest.mark.gpu
+
+KITTI_FX, KITTI_BF = 718.856, 386.1448     # Examples/Stereo/KITTI00-02.yaml:8,25
+
+
+@pytest.fixture(scope="module")
+def env(oracle):
+    import orb_slam2_comment_amd as pkg
+    from orb_slam2_comment_amd import matcher as M
+    return pkg, M, oracle
+
+
+def _views(pkg, O, img, kps, desc, sf, u_right=None):
+    keep = []
+    gv = pkg.FrameView(kps, desc, sf, frame_bounds(img), u_right)
+    ov = O.make_frame(kps, desc, u_right, frame_bounds(img), sf, keep)
+    return gv, ov, keep
+
+
+def test_descriptor_distance_matrix(env):
+    pkg, M, O = env
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (257, 32), dtype=np.uint8)
+    b[0] = a[0]; b[1] = ~a[1]
+    m = pkg.ORBmatcher()
+    d = m.DescriptorDistance(a, b)
+    ref = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+    assert np.array_equal(d, ref)
+    assert d[0, 0] == 0 and d[1, 1] == 256
+    for i in (0, 5, 17):
+        assert d[i, 3] == O.descriptor_distance(a[i], b[3])
+
+
+@pytest.mark.parametrize("W,H,nf,shift,window", [(752, 480, 2000, 5, 100), (640, 480, 1000, 12, 30),
+                                                  (1241, 376, 2000, 3, 100)])
+def test_search_for_initialization(env, W, H, nf, shift, window):
+    """configs[4]: EuRoC 752x480 @2000 + SearchForInitialization(windowSize=100, nnratio 0.9)
+    (src/Tracking.cc:599-600)."""
+    pkg, M, O = env
+    ext = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    img1, img2 = synth_frame(1, W, H), synth_frame(1, W, H, shift_xy=(shift, 0))
+    k1, d1 = ext(img1)
+    k2, d2 = ext(img2)
+    sf = ext.GetScaleFactors()
+    g1, o1, keep1 = _views(pkg, O, img1, k1, d1, sf)
+    g2, o2, keep2 = _views(pkg, O, img2, k2, d2, sf)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    for nnratio, ori in ((0.9, True), (0.6, False)):
+        m = pkg.ORBmatcher(nnratio, ori)
+        n, m12, pm = m.SearchForInitialization(g1, g2, prev, window)
+        on, om12, opm = O.search_for_initialization(o1, o2, prev, window, nnratio, ori)
+        assert n == on and np.array_equal(m12, om12)
+        assert np.array_equal(pm, opm)
+        assert n > 50
+        # second round from the updated vbPrevMatched (Tracking calls it once per frame)
+        n2, m12b, _ = m.SearchForInitialization(g1, g2, pm, window)
+        on2, om12b, _ = O.search_for_initialization(o1, o2, opm, window, nnratio, ori)
+        assert n2 == on2 and np.array_equal(m12b, om12b)
+
+
+def _queries_from_last_frame(M, img, k_last, sf, th, rng, bf=0.0, fwd=False, bwd=False, shift=3.0):
+    fx = fy = KITTI_FX
+    cx, cy = img.shape[1] / 2.0, img.shape[0] / 2.0
+    z = rng.uniform(4, 40, len(k_last)).astype(np.float32)
+    X = np.stack([(k_last["x"] - cx) * z / fx, (k_last["y"] - cy) * z / fy, z], 1).astype(np.float32)
+    Tcw = np.eye(4, dtype=np.float32)
+    Tcw[0, 3] = shift * 15.0 / fx          # ~shift px at 15 m
+    valid = rng.random(len(k_last)) < 0.85
+    observed = rng.random(len(k_last)) < 0.7
+    q = M.project_last_frame(Tcw, (fx, fy, cx, cy), (0, 0, img.shape[1], img.shape[0]), X, k_last["octave"],
+                             k_last["angle"], valid, observed, sf, th, mbf=bf, bForward=fwd, bBackward=bwd)
+    return q
+
+
+@pytest.mark.parametrize("th,stereo,fwd,bwd", [(15, False, False, False), (7, True, False, False),
+                                               (30, False, False, False), (7, True, True, False),
+                                               (7, True, False, True)])
+def test_search_by_projection_frame(env, th, stereo, fwd, bwd):
+    """configs[2]: SearchByProjection(CurrentFrame, LastFrame, th) on a KITTI-shape pair
+    (src/Tracking.cc:880-892: th 15 mono / 7 stereo, retry with 2*th)."""
+    pkg, M, O = env
+    rng = np.random.default_rng(th + 2 * stereo + 4 * fwd + 8 * bwd)
+    ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    img_last, img_cur = synth_frame(4), synth_frame(4, shift_xy=(3, 0))
+    k_last, d_last = ext(img_last)
+    k_cur, d_cur = ext(img_cur)
+    sf = ext.GetScaleFactors()
+    ur = None
+    if stereo:
+        ur = np.where(rng.random(len(k_cur)) < 0.6, k_cur["x"] - rng.uniform(2, 60, len(k_cur)), -1).astype(np.float32)
+    gv, ov, keep = _views(pkg, O, img_cur, k_cur, d_cur, sf, ur)
+    q = _queries_from_last_frame(M, img_cur, k_last, sf, th, rng, bf=KITTI_BF if stereo else 0.0, fwd=fwd, bwd=bwd)
+    taken = (rng.random(len(k_cur)) < 0.05).astype(np.uint8)
+    for ori in (True, False):
+        m = pkg.ORBmatcher(0.9, ori)
+        n, assign = m.SearchByProjectionFrame(gv, q, d_last, taken)
+        on, oassign = O.search_by_projection_frame(ov, q, d_last, taken, ori)
+        assert n == on and np.array_equal(assign, oassign)
+        assert n > 100
+    # no `taken` array, every query unobserved: later queries may overwrite earlier ones (:1428)
+    q2 = q.copy(); q2["observed"] = 0
+    n, assign = pkg.ORBmatcher(0.9, True).SearchByProjectionFrame(gv, q2, d_last)
+    on, oassign = O.search_by_projection_frame(ov, q2, d_last, None, True)
+    assert n == on and np.array_equal(assign, oassign)
+
+
+@pytest.mark.parametrize("th,nnratio", [(1, 0.8), (3, 0.8), (5, 0.8), (3, 0.6)])
+def test_search_by_projection_points(env, th, nnratio):
+    """SearchByProjection(F, vpMapPoints, th) as called from SearchLocalPoints
+    (src/Tracking.cc:1184-1191: nnratio 0.8, th 1/3/5)."""
+    pkg, M, O = env
+    rng = np.random.default_rng(int(th * 10 + nnratio * 100))
+    ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    img_map, img_cur = synth_frame(6), synth_frame(6, shift_xy=(2, 1))
+    k_map, d_map = ext(img_map)
+    k_cur, d_cur = ext(img_cur)
+    sf = ext.GetScaleFactors()
+    ur = np.where(rng.random(len(k_cur)) < 0.5, k_cur["x"] - rng.uniform(2, 60, len(k_cur)), -1).astype(np.float32)
+    gv, ov, keep = _views(pkg, O, img_cur, k_cur, d_cur, sf, ur)
+    nq = len(k_map)
+    q = np.zeros(nq, pkg.QUERY_DTYPE)
+    q["valid"] = rng.random(nq) < 0.9                       # mbTrackInView && !isBad()
+    q["u"] = k_map["x"] + 2 + rng.normal(0, 1.0, nq).astype(np.float32)
+    q["v"] = k_map["y"] + 1 + rng.normal(0, 1.0, nq).astype(np.float32)
+    pred = np.clip(k_map["octave"] + rng.integers(-1, 2, nq), 0, 7)
+    view_cos = rng.uniform(0.99, 1.0, nq)
+    r = np.array([M.RadiusByViewingCos(c) for c in view_cos], np.float32)
+    if th != 1.0:
+        r = r * np.float32(th)
+    q["radius"] = r * sf[pred]
+    q["min_level"], q["max_level"] = pred - 1, pred
+    q["ur"] = q["u"] - rng.uniform(2, 60, nq).astype(np.float32)
+    q["level_aux"] = pred
+    q["observed"] = rng.random(nq) < 0.8
+    taken = (rng.random(len(k_cur)) < 0.1).astype(np.uint8)
+    m = pkg.ORBmatcher(nnratio, True)
+    n, assign = m.SearchByProjectionPoints(gv, q, d_map, taken)
+    on, oassign = O.search_by_projection_points(ov, q, d_map, taken, nnratio)
+    assert n == on and np.array_equal(assign, oassign)
+    assert n > 50
+
+
+def test_matcher_degenerate_inputs(env):
+    pkg, M, O = env
+    ext = pkg.ORBextractor(500, 1.2, 8, 20, 7)
+    img = synth_frame(2, 640, 480)
+    k, d = ext(img)
+    sf = ext.GetScaleFactors()
+    gv, ov, keep = _views(pkg, O, img, k, d, sf)
+    m = pkg.ORBmatcher(0.9, True)
+    # no queries
+    n, a = m.SearchByProjectionFrame(gv, np.zeros(0, pkg.QUERY_DTYPE), np.zeros((0, 32), np.uint8))
+    assert n == 0 and np.all(a == -1)
+    # all queries invalid / far outside the image
+    q = np.zeros(10, pkg.QUERY_DTYPE)
+    q["valid"] = 1; q["u"] = 5000; q["v"] = 5000; q["radius"] = 10; q["min_level"] = -1; q["max_level"] = -1
+    n, a = m.SearchByProjectionFrame(gv, q, d[:10])
+    on, oa = O.search_by_projection_frame(ov, q, d[:10], None, True)
+    assert n == on == 0 and np.array_equal(a, oa)
+    # a query sitting on every keypoint with its own descriptor: everything matches at distance 0
+    q = np.zeros(len(k), pkg.QUERY_DTYPE)
+    q["valid"] = 1; q["u"] = k["x"]; q["v"] = k["y"]; q["radius"] = 3; q["min_level"] = -1; q["max_level"] = -1
+    q["angle"] = k["angle"]; q["observed"] = 1
+    n, a = m.SearchByProjectionFrame(gv, q, d)
+    on, oa = O.search_by_projection_frame(ov, q, d, None, True)
+    assert n == on and np.array_equal(a, oa) and n > 0.9 * len(k)
+    # huge window: more than 64 candidates per query exercises the unsorted path
+    q["radius"] = 400
+    q["observed"] = np.arange(len(k)) % 2
+    n, a = m.SearchByProjectionFrame(gv, q[:200], d[:200])
+    on, oa = O.search_by_projection_frame(ov, q[:200], d[:200], None, True)
+    assert n == on and np.array_equal(a, oa)
+    n, a = m.SearchByProjectionPoints(gv, q[:200], d[:200])
+    on, oa = O.search_by_projection_points(ov, q[:200], d[:200], None, 0.9)
+    assert n == on and np.array_equal(a, oa)
+
+
+@pytest.mark.parametrize("seed,W,H,nf", [(1, 1241, 376, 1000), (2, 1241, 376, 2000), (3, 752, 480, 1000)])
+def test_compute_stereo_matches(env, seed, W, H, nf):
+    """configs[2]: stereo_kitti-shape pair, Frame::ComputeStereoMatches (src/Frame.cc:466-640);
+    mb = mbf/fx as intended by the reference (src/Frame.cc:114)."""
+    pkg, M, O = env
+    left, right = synth_stereo(seed, W, H)
+    eL = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    eR = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    kl, dl = eL(left)
+    kr, dr = eR(right)
+    mbf = np.float32(KITTI_BF)
+    mb = np.float32(mbf / np.float32(KITTI_FX))
+    m = pkg.ORBmatcher()
+    n, ur, dp = m.ComputeStereoMatches(eL, eR, kl, dl, kr, dr, float(mbf), float(mb))
+    oL, oR = O.OracleExtractor(nf, 1.2, 8, 20, 7), O.OracleExtractor(nf, 1.2, 8, 20, 7)
+    okl, odl = oL.extract(left)
+    okr, odr = oR.extract(right)
+    lv_l = [np.ascontiguousarray(oL.level_padded(l))[19:-19, 19:-19] for l in range(8)]
+    lv_r = [np.ascontiguousarray(oR.level_padded(l))[19:-19, 19:-19] for l in range(8)]
+    t = oL.tables()
+    on, our, odp = O.compute_stereo_matches(okl, odl, okr, odr, lv_l, lv_r, t["scale"], t["inv_scale"], float(mbf), float(mb))
+    assert n == on and n > 100
+    assert np.array_equal(ur > 0, our > 0) and np.array_equal(dp > 0, odp > 0)
+    assert np.allclose(ur, our, rtol=1e-6, atol=0) and np.allclose(dp, odp, rtol=1e-6, atol=0)
+    assert np.array_equal(ur, our) and np.array_equal(dp, odp)     # in practice bit-identical
+    # disparity sanity: uL - uR within the scene's [2, 80] px layers (+- sub-pixel refinement)
+    disp = kl["x"][ur > 0] - ur[ur > 0]
+    assert np.all(disp >= 0) and np.median(disp) > 2 and np.percentile(disp, 90) < 90   # a few false matches reach maxD

@@ -1,0 +1,268 @@
+"""Oracle vs the known answers derivable from the reference text and
+vs independent restatements (numpy) of each primitive.  CPU only."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from orb_slam2_comment_amd.synth import synth_frame
+
+
+def test_quotas_umax_scales(oracle):
+    e = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    t = e.tables()
+    # src/ORBextractor.cc:435-446
+    assert t["feat"].tolist() == [217, 181, 151, 126, 105, 87, 73, 60]
+    # :454-469
+    assert t["umax"].tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert 2 * sum(2 * u + 1 for u in t["umax"][1:]) + 31 == 749
+    # :415-431, float32 tables printed by the reference constructor
+    exp = np.array([1, 1.20000005, 1.44000006, 1.72800016, 2.07360029, 2.48832035, 2.98598456, 3.58318162], np.float32)
+    assert np.array_equal(t["scale"], exp)
+    inv = np.array([1, 0.833333313, 0.694444418, 0.578703642, 0.482253015, 0.401877522, 0.334897906, 0.279081583], np.float32)
+    assert np.array_equal(t["inv_scale"], inv)
+    e2 = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    assert e2.tables()["feat"].tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+
+
+@pytest.mark.parametrize("wh,sizes", [
+    ((1241, 376), [(1241, 376), (1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)]),
+    ((752, 480), [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]),
+])
+def test_pyramid_sizes_and_keypoint_size(oracle, wh, sizes):
+    e = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    kps, desc = e.extract(synth_frame(3, *wh))
+    assert [e.level_size(l) for l in range(8)] == sizes   # :1111-1112
+    size_by_level = [31, 37, 44, 53, 64, 77, 92, 111]      # :837,846
+    for l in range(8):
+        lk = e.level_keypoints(l)
+        assert np.all(lk["size"] == size_by_level[l])
+        assert np.all(lk["octave"] == l)
+        w, h = sizes[l]
+        assert np.all((lk["x"] >= 19) & (lk["x"] < w - 19) & (lk["y"] >= 19) & (lk["y"] < h - 19))
+        assert len(lk) <= e.tables()["feat"][l] + 3
+    assert desc.shape == (len(kps), 32)
+    assert np.all(kps["class_id"] == -1)
+    assert np.all((kps["angle"] >= 0) & (kps["angle"] <= 360))
+
+
+def test_pattern_table():
+    import re
+    txt = open("oracle/rbrief_pattern.h").read()
+    vals = [int(v) for v in re.findall(r"-?\d+", txt.split("{", 1)[1].split("}")[0])]
+    assert len(vals) == 1024 and vals[:4] == [8, -3, 9, 5]        # pattern[0]=(8,-3), pattern[1]=(9,5)
+    assert min(vals) == -13 and max(vals) <= 13
+    r = max(math.hypot(vals[i], vals[i + 1]) for i in range(0, 1024, 2))
+    assert 18.3 < r < 18.4                                        # < EDGE_THRESHOLD
+    prod = open("orb_slam2_comment_amd/csrc/rbrief_pattern.h").read()
+    assert [int(v) for v in re.findall(r"-?\d+", prod.split("{", 1)[1].split("}")[0])] == vals
+
+
+def test_cvround_ties_to_even(oracle):
+    L = oracle.lib()
+    assert [L.oracle_cvround(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 2.5001)] == [0, 2, 2, 0, -2, 2, 3]
+
+
+def test_hamming_swar_is_popcount(oracle):
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+    for i in range(200):
+        assert oracle.descriptor_distance(a[i], b[i]) == int(np.unpackbits(a[i] ^ b[i]).sum())
+    assert oracle.descriptor_distance(a[0], a[0]) == 0
+    assert oracle.descriptor_distance(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+
+
+def test_fast_atan2_accuracy(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(1)
+    for _ in range(2000):
+        y, x = rng.normal(size=2) * 1000
+        a = L.oracle_fast_atan2(y, x)
+        ref = math.degrees(math.atan2(y, x)) % 360
+        d = abs(a - ref)
+        assert min(d, 360 - d) < 0.3
+    assert L.oracle_fast_atan2(0.0, 1.0) == 0.0
+    assert abs(L.oracle_fast_atan2(1.0, 0.0) - 90) < 0.01
+
+
+def test_det_sincos_vs_libm_float(oracle):
+    """det_sincos is the correctly rounded float sin/cos.  glibc's cosf/sinf (what
+    `(float)cos(float)` resolves to, src/ORBextractor.cc:113) is faithful but not correctly
+    rounded, so ~1-2 % of angles differ by one ulp -- the reference's own platform dependence.
+    The descriptor-level effect is measured below."""
+    L = oracle.lib()
+    libm = C.CDLL("libm.so.6")
+    libm.cosf.restype = C.c_float; libm.cosf.argtypes = [C.c_float]
+    libm.sinf.restype = C.c_float; libm.sinf.argtypes = [C.c_float]
+    c, s = C.c_float(), C.c_float()
+    bad = 0
+    angles = np.linspace(0, 360, 20001, dtype=np.float32) * np.float32(math.pi / 180.0)
+    for a in angles:
+        L.oracle_det_sincos(float(a), C.byref(c), C.byref(s))
+        bad += (c.value != libm.cosf(float(a))) + (s.value != libm.sinf(float(a)))
+        # correctly rounded: equals the float nearest to the double-precision value
+        assert c.value == np.float32(math.cos(float(a))) and s.value == np.float32(math.sin(float(a)))
+        assert abs(c.value - libm.cosf(float(a))) <= 6e-8 and abs(s.value - libm.sinf(float(a))) <= 6e-8
+    assert bad <= 0.03 * 2 * len(angles), bad
+
+
+def test_descriptor_sensitivity_to_libm(oracle):
+    """Swapping det_sincos for this platform's libm changes at most a handful of descriptor
+    bits per frame (a tap flips only when its rotated coordinate sits within 1e-6 of x.5)."""
+    e = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    img = synth_frame(1)
+    k1, d1 = e.extract(img)
+    oracle.lib().oracle_use_libm_sincos(1)
+    try:
+        k2, d2 = e.extract(img)
+    finally:
+        oracle.lib().oracle_use_libm_sincos(0)
+    assert all(np.array_equal(k1[f], k2[f]) for f in k1.dtype.names)
+    flipped = int(np.unpackbits(d1 ^ d2).sum())
+    assert flipped <= 8, flipped
+
+
+def test_resize_properties(oracle):
+    L = oracle.lib()
+    src = np.full((50, 60), 137, np.uint8)
+    dst = np.zeros((42, 50), np.uint8)
+    L.oracle_resize_linear(src.ctypes.data, 60, 60, 50, dst.ctypes.data, 50, 50, 42)
+    assert np.all(dst == 137)
+    # independent numpy restatement of the fixed-point bilinear formula
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    dw, dh = 44, 31
+    dst = np.zeros((dh, dw), np.uint8)
+    L.oracle_resize_linear(src.ctypes.data, 53, 53, 37, dst.ctypes.data, dw, dw, dh)
+
+    def taps(d, s):
+        scale = 1.0 / (d / s)
+        f = ((np.arange(d) + 0.5) * scale - 0.5).astype(np.float32)
+        i = np.floor(f).astype(int)
+        f = (f - i).astype(np.float32)
+        return i, f
+    sx, fx = taps(dw, 53)
+    lo, hi = sx < 0, sx >= 52
+    fx[lo | hi] = 0; sx[lo] = 0; sx[hi] = 52
+    a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(int); a1 = np.rint(fx * np.float32(2048)).astype(int)
+    sy, fy = taps(dh, 37)
+    b0 = np.rint((np.float32(1) - fy) * np.float32(2048)).astype(int); b1 = np.rint(fy * np.float32(2048)).astype(int)
+    y0 = np.clip(sy, 0, 36); y1 = np.clip(sy + 1, 0, 36)
+    S = src.astype(int)
+    x1 = np.minimum(sx + 1, 52)
+    H = S[:, sx] * a0 + S[:, x1] * a1
+    out = (((b0[:, None] * (H[y0] >> 4)) >> 16) + ((b1[:, None] * (H[y1] >> 4)) >> 16) + 2) >> 2
+    assert np.array_equal(dst, out.astype(np.uint8))
+
+
+def test_gauss7_matches_numpy(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(6)
+    src = rng.integers(0, 256, (40, 45), dtype=np.uint8)
+    dst = np.zeros_like(src)
+    L.oracle_gauss7(src.ctypes.data, 45, 45, 40, dst.ctypes.data, 45)
+    w = np.array([18, 34, 49, 55, 49, 34, 18])
+    p = np.pad(src.astype(int), 3, mode="reflect")      # numpy 'reflect' == BORDER_REFLECT_101
+    rows = sum(w[k] * p[:, k:k + 45] for k in range(7))
+    out = sum(w[k] * rows[k:k + 40] for k in range(7))
+    assert np.array_equal(dst, np.minimum((out + 32768) >> 16, 255).astype(np.uint8))
+    white = np.full((20, 20), 255, np.uint8); o = np.zeros_like(white)
+    L.oracle_gauss7(white.ctypes.data, 20, 20, 20, o.ctypes.data, 20)
+    assert np.all(o == 255)       # weights sum to 257: saturates, does not wrap
+
+
+def _fast_bruteforce(img, t):
+    """Independent FAST-9/16: segment test + score by exhaustive threshold search."""
+    off = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+           (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    h, w = img.shape
+    I = img.astype(int)
+
+    def corner(y, x, th):
+        v = I[y, x]
+        ring = [I[y + dy, x + dx] for dx, dy in off]
+        for sign in (1, -1):
+            m = [(sign * (p - v)) > th for p in ring] * 2
+            run = 0
+            for b in m:
+                run = run + 1 if b else 0
+                if run >= 9:
+                    return True
+        return False
+    score = np.zeros((h, w), int)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            if corner(y, x, t):
+                s = t
+                while s < 255 and corner(y, x, s + 1):
+                    s += 1
+                score[y, x] = s
+    out = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            s = score[y, x]
+            if s and all(s > score[y + dy, x + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if dy or dx):
+                out.append((x, y, s))
+    return out
+
+
+@pytest.mark.parametrize("seed,t", [(1, 20), (2, 7), (3, 20), (4, 7)])
+def test_fast_matches_bruteforce(oracle, seed, t):
+    L = oracle.lib()
+    img = np.ascontiguousarray(synth_frame(seed, 160, 120)[40:78, 60:97])   # one 37x38 cell
+    h, w = img.shape
+    ox, oy, os_ = (np.zeros(w * h, np.int32) for _ in range(3))
+    n = L.oracle_fast(img.ctypes.data, w, w, h, t, 1, ox.ctypes.data, oy.ctypes.data, os_.ctypes.data)
+    got = list(zip(ox[:n].tolist(), oy[:n].tolist(), os_[:n].tolist()))
+    assert got == _fast_bruteforce(img, t)
+
+
+def test_octree_properties(oracle):
+    L = oracle.lib()
+    e = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    e.extract(synth_frame(2))
+    for level in range(8):
+        x, y, r = e.level_candidates(level)
+        w, h = e.level_size(level)
+        N = int(e.tables()["feat"][level])
+        out = np.zeros(N + 64, np.int32)
+        n = L.oracle_distribute_octree(x.ctypes.data, y.ctypes.data, r.ctypes.data, len(x), 16, w - 16, 16, h - 16,
+                                       N, out.ctypes.data, len(out))
+        assert N <= n <= N + 2 or n == len(x)
+        sel = out[:n]
+        assert len(set(sel.tolist())) == n
+        # a selected key is never dominated by a stronger key at the same position
+        assert np.all(r[sel] >= 7)
+    # fewer keys than N: every key is kept, one per node
+    idx = np.zeros(16, np.int32)
+    xs = np.array([5, 50, 100, 200], np.float32); ys = np.array([5, 20, 40, 60], np.float32); rs = np.array([9, 8, 7, 30], np.float32)
+    n = L.oracle_distribute_octree(xs.ctypes.data, ys.ctypes.data, rs.ctypes.data, 4, 16, 316, 16, 116, 50, idx.ctypes.data, 16)
+    assert n == 4 and sorted(idx[:4].tolist()) == [0, 1, 2, 3]
+
+
+def test_three_maxima(oracle):
+    L = oracle.lib()
+    h = np.zeros(30, np.int32); h[3] = 50; h[7] = 20; h[9] = 4
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    L.oracle_three_maxima(h.ctypes.data, 30, C.byref(a), C.byref(b), C.byref(c))
+    assert (a.value, b.value, c.value) == (3, 7, -1)      # 4 < 0.1*50 -> third dropped (:1638-1641)
+    h[7] = 4
+    L.oracle_three_maxima(h.ctypes.data, 30, C.byref(a), C.byref(b), C.byref(c))
+    assert (a.value, b.value, c.value) == (3, -1, -1)
+
+
+def test_extract_is_deterministic_and_translation_consistent(oracle):
+    e = oracle.OracleExtractor(500, 1.2, 8, 20, 7)
+    img = synth_frame(5, 320, 240)
+    k1, d1 = e.extract(img)
+    k2, d2 = e.extract(img.copy())
+    assert np.array_equal(d1, d2) and all(np.array_equal(k1[f], k2[f]) for f in k1.dtype.names)
+    assert 480 <= len(k1) <= 500 + 24
+    # empty image -> silent return (:1046)
+    k0, d0 = e.extract(np.zeros((0, 0), np.uint8))
+    assert len(k0) == 0
+    # flat image -> no corners at all
+    kf, _ = e.extract(np.full((240, 320), 128, np.uint8))
+    assert len(kf) == 0
