@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the ORB front-end on synthetic KITTI-shape frames.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-gpu B]
+
+Workload (BASELINE.json configs[1]): synthetic 1241x376 uint8 frames already resident in
+HBM, nFeatures=1000, scaleFactor 1.2, 8 levels, iniThFAST 20 / minThFAST 7, extract-only.
+One "step" = one pass of ORBextractor::operator() over a batch of B frames per GPU.
+For N>1 (launched by torch.distributed.run, one rank per GPU) frame i of the global batch
+goes to rank i mod N, every rank extracts its shard, and each step ends with the RCCL gather
+of the fixed-capacity (count, keypoints, descriptors) slots to rank 0 (configs[3]).
+
+Rank 0 prints ONE JSON line; see README/DESIGN.md for the roofline and cpu_baseline objects.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NFEAT, NLEVELS = 1241, 376, 1000, 8
+LEVEL_PX = [1241 * 376, 1034 * 313, 862 * 261, 718 * 218, 598 * 181, 499 * 151, 416 * 126, 346 * 105]
+SUM_P = sum(LEVEL_PX)                                   # 1,444,097 px
+# algorithmic bytes per frame of each stage (stage-materialised model)
+ALGO_BYTES = {
+    "pyramid": LEVEL_PX[0] + (SUM_P - LEVEL_PX[7]) + SUM_P,   # K1: reads P0 + (SumP-P7), writes SumP
+    "fast": SUM_P,                                            # K2+K3: reads SumP
+    "blur": 2 * SUM_P,                                        # K6: reads + writes SumP
+    "describe": NFEAT * (749 + 512) + NFEAT * 60,             # K5+K7: gathers + 60 B out per keypoint
+    "octree": 0,
+}
+FRAME_BYTES_MODEL = 8971771                             # BASELINE.md section 3, whole path
+HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(frames, budget_s=20.0):
+    """Oracle (plain-C port of the reference algorithm, oracle/orb_oracle.c) on the host cores:
+    one extractor instance per thread on a bounded sample of the same workload."""
+    from oracle import oracle_py as O
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    O.lib()
+    warm = O.OracleExtractor(NFEAT, 1.2, NLEVELS, 20, 7)
+    warm.extract(frames[0])
+    t0 = time.perf_counter()
+    warm.extract(frames[0])                                            # single-thread estimate
+    one = time.perf_counter() - t0
+    per_thread = int(max(4, min(400, budget_s / max(one, 1e-3))))   # ~budget_s of wall, all threads busy
+    done = [0] * cores
+
+    def work(t):
+        e = O.OracleExtractor(NFEAT, 1.2, NLEVELS, 20, 7)
+        for i in range(per_thread):
+            e.extract(frames[(t * per_thread + i) % len(frames)])
+            done[t] += 1
+    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    total = sum(done)
+    return {"value": round(total / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frames 1241x376 (%d per thread x %d threads), %.1f s wall; scalar C port, "
+                      "not OpenCV SIMD" % (total, per_thread, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-gpu", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0 and not os.path.exists(os.path.join(ROOT, "orb_slam2_comment_amd", "liborbhip.so")):
+        g.build()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from orb_slam2_comment_amd import ORBextractor
+    from orb_slam2_comment_amd.sharding import gather_to_rank0, shard_indices
+    from orb_slam2_comment_amd.synth import synth_frame
+
+    B = args.frames_per_gpu
+    # global batch of B*world frames; rank r owns frames r, r+world, ... (16 distinct seeds, tiled)
+    mine = shard_indices(B * world, rank, world)
+    uniq = {}
+    for gidx in mine:
+        s = 1 + gidx % 16
+        if s not in uniq:
+            uniq[s] = synth_frame(s, W, H)
+    frames = np.stack([uniq[1 + gidx % 16] for gidx in mine])
+    d_img = torch.from_numpy(frames).to(dev)
+
+    ext = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ext.set_stream(stream.cuda_stream)          # launches go to torch's current stream
+    cap = ext.capacity(H, W)
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.int32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def step():
+        ext.extract_batch_device(d_img.data_ptr(), B, H, W, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                 d_n.data_ptr(), d_st.data_ptr())
+        if world > 1:
+            return gather_to_rank0(d_kps, d_desc, d_n)
+        return None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ext.set_profiling(True)                     # HIP events around every stage, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stage = ext.stage_times_us()
+    ext.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_host = d_n.cpu().numpy()
+    assert int(d_st.abs().sum().item()) == 0 and n_host.min() > 0, "extraction failed"
+
+    if rank == 0:
+        total_frames = B * world * args.steps
+        fps = total_frames / dt
+        kern = max(("pyramid", "fast", "octree", "blur", "describe"), key=lambda k: stage[k])
+        if ALGO_BYTES[kern] == 0:   # the octree moves no pixel data: price the next stage instead
+            kern = max(("pyramid", "fast", "blur", "describe"), key=lambda k: stage[k])
+        algo = ALGO_BYTES[kern] * B
+        achieved = algo / (stage[kern] * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(kern, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "frames/sec ORB extract, KITTI 1241x376 @1000 feat (extract-only, configs[1])",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic 1241x376 u8 frames resident in HBM, nFeatures=1000, "
+                                   "8-level pyramid, extract-only" +
+                                   ("; configs[3]: one frame per GPU round-robin + RCCL gather to rank 0" if world > 1 else ""),
+                       "frames_per_gpu_per_step": B, "global_batch": B * world, "nfeatures": NFEAT,
+                       "levels": NLEVELS, "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
+                       "parallelism": "frame-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_pyr_level0+k_pyr_resize(x7)", "fast": "k_fast_cells",
+                                                    "blur": "k_blur", "describe": "k_orient_describe"}[kern],
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo,
+                         "avg_launch_us": round(stage[kern], 2),
+                         "stage_us": {k: round(v, 2) for k, v in stage.items()},
+                         "whole_path_GBps_model": round(FRAME_BYTES_MODEL * B / (stage["total"] * 1e-6) / 1e9, 2)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(frames[:16])
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

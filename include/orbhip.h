@@ -92,6 +92,8 @@ int orbhip_extract_batch_device(orbhip_extractor *e, const void *d_images, int b
                                 void *d_desc, int cap, void *d_n, void *d_status);
 int orbhip_extractor_sync(orbhip_extractor *e);
 void *orbhip_extractor_stream(orbhip_extractor *e); /* hipStream_t */
+/* Launch on a caller-owned hipStream_t instead (NULL: back to the handle's own stream). */
+int orbhip_extractor_set_stream(orbhip_extractor *e, void *stream);
 
 /* mvImagePyramid[level] of frame `frame` of the last extract call: size and device pointer of
  * the level ROI (valid until the next extract on this handle); row stride in bytes.  The ROI is
@@ -109,9 +111,10 @@ int orbhip_blurred_level_download(orbhip_extractor *e, int frame, int level, uin
 int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *x, int32_t *y,
                             int32_t *score, int cap, int *n);
 
-/* Per-stage device time of the last (batched) extract, microseconds, measured with HIP events
- * on the handle's stream: [0] pyramid, [1] FAST+NMS cells, [2] octree, [3] blur,
- * [4] orientation+descriptors, [5] total.  Enabled by orbhip_extractor_set_profiling(e, 1). */
+/* Per-stage device time, microseconds, averaged over the extract calls made since
+ * orbhip_extractor_set_profiling(e, 1) (at most the last 256), measured with HIP events on the
+ * handle's stream: [0] pyramid (8 launches), [1] FAST+NMS cells, [2] octree, [3] blur,
+ * [4] orientation+descriptors, [5] whole call. */
 int orbhip_extractor_set_profiling(orbhip_extractor *e, int on);
 int orbhip_extractor_stage_times(orbhip_extractor *e, float us[6]);
 

@@ -48,6 +48,7 @@ SYMBOLS = [
     ("orbhip_extract_batch_device", _i, [_vp, _vp, _i, _i, _i, _i, _sz, _vp, _vp, _i, _vp, _vp]),
     ("orbhip_extractor_sync", _i, [_vp]),
     ("orbhip_extractor_stream", _vp, [_vp]),
+    ("orbhip_extractor_set_stream", _i, [_vp, _vp]),
     ("orbhip_pyramid_level", _i, [_vp, _i, _i, _pi, _pi, _pi, C.POINTER(_vp)]),
     ("orbhip_pyramid_level_download", _i, [_vp, _i, _i, _i, _vp, _i]),
     ("orbhip_blurred_level_download", _i, [_vp, _i, _i, _vp, _i]),

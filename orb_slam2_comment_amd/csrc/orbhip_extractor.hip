@@ -942,9 +942,10 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     const PyrGeom &G = e->G;
     hipStream_t s = e->stream;
     const bool prof = e->profiling;
+    hipEvent_t *ev = prof ? &e->ev[(size_t)(e->prof_calls % orbhip_extractor::kProfRing) * 6] : nullptr;
     int *status = d_status ? d_status : e->d_status;
     hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
-    if (prof) hipEventRecord(e->ev[0], s);
+    if (prof) hipEventRecord(ev[0], s);
     {
         const LevelGeom &L = G.lv[0];
         int n = (L.pitch >> 2) * L.prows;
@@ -956,24 +957,24 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
             hipLaunchKernelGGL(k_pyr_resize, dim3((nl + 255) / 256, batch), dim3(256), 0, s, e->d_pyr, G, l, e->d_tabs);
         }
     }
-    if (prof) hipEventRecord(e->ev[1], s);
+    if (prof) hipEventRecord(ev[1], s);
     if (G.ncells_total > 0)
         hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, batch), dim3(256), 0, s, e->d_pyr, G, e->d_cells,
                            e->d_cell_cnt, e->d_cell_kp);
-    if (prof) hipEventRecord(e->ev[2], s);
+    if (prof) hipEventRecord(ev[2], s);
     if (e->octree_maxn == 512)
         hipLaunchKernelGGL(k_octree<512>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
                            e->d_keys, e->d_knode, e->d_sel, e->d_sel_cnt, status);
     else
         hipLaunchKernelGGL(k_octree<2048>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
                            e->d_keys, e->d_knode, e->d_sel, e->d_sel_cnt, status);
-    if (prof) hipEventRecord(e->ev[3], s);
+    if (prof) hipEventRecord(ev[3], s);
     hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, e->d_pyr, e->d_blur, G,
                        e->d_tiles, e->blurw);
-    if (prof) hipEventRecord(e->ev[4], s);
+    if (prof) hipEventRecord(ev[4], s);
     hipLaunchKernelGGL(k_orient_describe, dim3((G.kp_cap_total + 3) / 4, batch), dim3(256), 0, s, e->d_pyr, e->d_blur,
                        G, e->d_sel, e->d_sel_cnt, e->d_disc, e->d_pattern, d_kps, d_desc, cap, d_n, status);
-    if (prof) { hipEventRecord(e->ev[5], s); e->have_times = true; }
+    if (prof) { hipEventRecord(ev[5], s); e->prof_calls++; }
     e->last_batch = batch;
     ORBHIP_HIP_CHECK(hipGetLastError());
     return ORBHIP_OK;
@@ -1027,12 +1028,12 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
     const int bw[7] = {18, 34, 49, 55, 49, 34, 18};
     for (int i = 0; i < 7; ++i) e->blurw.w[i] = bw[i];
 
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("hipSetDevice/hipStreamCreate failed");
         delete e;
         return ORBHIP_E_HIP;
     }
-    for (int i = 0; i < 6; ++i) hipEventCreate(&e->ev[i]);
+    e->stream = e->own_stream;
     // disc offsets in the reference's traversal order (order is irrelevant for integer sums)
     DiscTab dt; memset(&dt, 0, sizeof(dt));
     int nd = 0;
@@ -1062,8 +1063,8 @@ void orbhip_extractor_destroy(orbhip_extractor *e)
     free_geometry(e);
     free_batch(e);
     hipFree(e->d_disc); hipFree(e->d_pattern); hipFree(e->d_img); hipFree(e->d_okp); hipFree(e->d_odesc); hipFree(e->d_on);
-    for (int i = 0; i < 6; ++i) if (e->ev[i]) hipEventDestroy(e->ev[i]);
-    if (e->stream) hipStreamDestroy(e->stream);
+    for (hipEvent_t v : e->ev) hipEventDestroy(v);
+    if (e->own_stream) hipStreamDestroy(e->own_stream);
     delete e;
 }
 
@@ -1191,6 +1192,15 @@ int orbhip_extractor_sync(orbhip_extractor *e)
 
 void *orbhip_extractor_stream(orbhip_extractor *e) { return e ? (void *)e->stream : nullptr; }
 
+int orbhip_extractor_set_stream(orbhip_extractor *e, void *stream)
+{
+    if (!e) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->stream = stream ? (hipStream_t)stream : e->own_stream;
+    return ORBHIP_OK;
+}
+
 int orbhip_pyramid_level(orbhip_extractor *e, int frame, int level, int *rows, int *cols, int *stride, const void **d_roi)
 {
     if (!e || !e->bound || frame < 0 || frame >= e->last_batch || level < 0 || level >= e->nlevels) return ORBHIP_E_ARG;
@@ -1254,24 +1264,35 @@ int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *
 int orbhip_extractor_set_profiling(orbhip_extractor *e, int on)
 {
     if (!e) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    if (on && e->ev.empty()) {
+        e->ev.resize((size_t)orbhip_extractor::kProfRing * 6);
+        for (auto &v : e->ev) ORBHIP_HIP_CHECK(hipEventCreate(&v));
+    }
     e->profiling = on != 0;
-    e->have_times = false;
+    e->prof_calls = 0;
     return ORBHIP_OK;
 }
 
 int orbhip_extractor_stage_times(orbhip_extractor *e, float us[6])
 {
-    if (!e || !us || !e->have_times) return ORBHIP_E_ARG;
+    if (!e || !us || e->prof_calls == 0) return ORBHIP_E_ARG;
     ORBHIP_HIP_CHECK(hipSetDevice(e->device));
-    ORBHIP_HIP_CHECK(hipEventSynchronize(e->ev[5]));
-    for (int i = 0; i < 5; ++i) {
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    const long n = std::min<long>(e->prof_calls, orbhip_extractor::kProfRing);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (long c = 0; c < n; ++c) {
+        hipEvent_t *ev = &e->ev[(size_t)c * 6];
+        for (int i = 0; i < 5; ++i) {
+            float ms = 0;
+            ORBHIP_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            acc[i] += ms * 1000.0;
+        }
         float ms = 0;
-        ORBHIP_HIP_CHECK(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
-        us[i] = ms * 1000.f;
+        ORBHIP_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[5]));
+        acc[5] += ms * 1000.0;
     }
-    float ms = 0;
-    ORBHIP_HIP_CHECK(hipEventElapsedTime(&ms, e->ev[0], e->ev[5]));
-    us[5] = ms * 1000.f;
+    for (int i = 0; i < 6; ++i) us[i] = (float)(acc[i] / n);
     return ORBHIP_OK;
 }
 

@@ -19,10 +19,13 @@ struct orbhip_extractor {
     int nfeat[ORBHIP_MAX_LEVELS];
     int umax[orbhip::kHalfPatch + 1];
     orbhip::BlurW blurw;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool profiling = false, have_times = false;
-    float times[6] = {0, 0, 0, 0, 0, 0};
+    hipStream_t stream = nullptr;       // stream every launch of this handle goes to
+    hipStream_t own_stream = nullptr;   // created with the handle; `stream` may be re-pointed
+    // profiling: ring of event sets (6 events per extract call), averaged on read-out
+    static constexpr int kProfRing = 256;
+    std::vector<hipEvent_t> ev;         // kProfRing * 6, created lazily
+    bool profiling = false;
+    long prof_calls = 0;
 
     // geometry (bound to an image size)
     bool bound = false;

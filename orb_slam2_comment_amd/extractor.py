@@ -129,6 +129,10 @@ class ORBextractor:
     def stream(self):
         return self._lib.orbhip_extractor_stream(self._h)
 
+    def set_stream(self, stream):
+        """stream: hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream), 0 = handle's own."""
+        check(self._lib.orbhip_extractor_set_stream(self._h, stream), "orbhip_extractor_set_stream")
+
     def set_profiling(self, on=True):
         check(self._lib.orbhip_extractor_set_profiling(self._h, int(on)), "orbhip_extractor_set_profiling")
 
