@@ -85,6 +85,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
                               % LIB_PATH)
+        # torch bundles its own libamdhip64.so.7 (same soname as /opt/rocm's).  Whichever copy is
+        # loaded first serves the whole process, and torch cannot see the GPU through the system
+        # copy -- so when torch is installed, let it load its runtime before liborbhip.so binds.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the export is missing

@@ -189,67 +189,32 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
 
 // ---------------------------------------------------------------------------
 // K2+K3: FAST-9/16 + NMS, one workgroup per reference cell (= one cv::FAST call,
-// ORBextractor.cc:789-829).  The (wCell+6)x(hCell+6) sub-image is staged in LDS;
-// the threshold-independent score S = max(dark,bright)-1 is computed for every
-// pixel that is a corner at minThFAST (others hold 0); NMS runs at iniThFAST and
-// falls back to minThFAST when the cell keeps nothing (:812-816).  Neighbours
-// outside the detection rectangle count as 0, exactly like the reference's
-// zero-initialised score rows.  Survivors are emitted in row-major order.
+// ORBextractor.cc:789-829).  The (wCell+6)x(hCell+6) sub-image is staged in LDS with
+// aligned dword loads; every thread owns 4 horizontally adjacent pixels (one LDS dword
+// column group) and reads its 7x12-byte neighbourhood as 21 dwords.  The
+// threshold-independent score S = max(dark,bright)-1 (cornerScore<16>) is computed with
+// min3/max3 networks for pixels that pass the compass pre-test at minThFAST (others
+// hold 0); NMS runs at iniThFAST and falls back to minThFAST when the cell keeps nothing
+// (:812-816).  Neighbours outside the detection rectangle count as 0, exactly like the
+// reference's zero-initialised score rows.  Survivors are emitted in row-major order.
 // ---------------------------------------------------------------------------
-constexpr int kSubMax = 72;            // max (wCell+6), (hCell+6)
-constexpr int kSubStride = kSubMax;    // LDS row stride of the sub-image
-constexpr int kScoreStride = kSubMax;  // detection rect + 1-px zero halo fits (<= 66+2)
+constexpr int kSubMax = 72;              // max (wCell+6), (hCell+6)
+constexpr int kFStride = 84;             // LDS row stride in bytes (21 dwords): 4 margin + <=75 + spare
+constexpr int kFStrideW = kFStride / 4;
 
-__device__ __forceinline__ bool has_arc9(uint32_t m16)
-{
-    uint32_t m = m16 | (m16 << 16);
-    uint32_t a = m & (m >> 1);
-    a &= a >> 2;   // 4 consecutive
-    a &= a >> 4;   // 8 consecutive
-    a &= m >> 8;   // 9 consecutive
-    return (a & 0xffffu) != 0;
-}
-
-__device__ __forceinline__ int fast_score(const uint8_t *c, int v)
-{
-    // ring offsets (dx,dy) k=0..15 as cv::FAST: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)
-    // (0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-    int d[16];
-    d[0] = v - c[3 * kSubStride];      d[1] = v - c[3 * kSubStride + 1];
-    d[2] = v - c[2 * kSubStride + 2];  d[3] = v - c[kSubStride + 3];
-    d[4] = v - c[3];                   d[5] = v - c[-kSubStride + 3];
-    d[6] = v - c[-2 * kSubStride + 2]; d[7] = v - c[-3 * kSubStride + 1];
-    d[8] = v - c[-3 * kSubStride];     d[9] = v - c[-3 * kSubStride - 1];
-    d[10] = v - c[-2 * kSubStride - 2]; d[11] = v - c[-kSubStride - 3];
-    d[12] = v - c[-3];                 d[13] = v - c[kSubStride - 3];
-    d[14] = v - c[2 * kSubStride - 2]; d[15] = v - c[3 * kSubStride - 1];
-    // dark = max over the 16 arcs of min(d), bright = max over arcs of min(-d) = -min over arcs of max(d)
-    int mn2[16], mx2[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-    int mn4[16], mx4[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-    int dark = -1000, brightneg = 1000;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-        dark = max(dark, mn9);
-        brightneg = min(brightneg, mx9);
-    }
-    return max(dark, -brightneg) - 1;
-}
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+// byte `o` (0..11) of the 12-byte window {w0,w1,w2}
+#define ORB_BYTE(w0, w1, w2, o) ((int)((((o) < 4 ? (w0) : (o) < 8 ? (w1) : (w2)) >> (8 * ((o) & 3))) & 0xffu))
 
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, PyrGeom G,
                                                     const CellDesc *__restrict__ cells,
                                                     int *__restrict__ cell_cnt,
                                                     uint32_t *__restrict__ cell_kp)
 {
-    __shared__ uint8_t simg[kSubMax * kSubStride];
-    __shared__ uint8_t sscore[(kSubMax + 2) * kScoreStride];
-    __shared__ int swave[4];
-    __shared__ int sbase;
+    __shared__ uint32_t simg[kSubMax * kFStrideW];
+    __shared__ uint32_t sscore[(kSubMax + 2) * kFStrideW];
+    __shared__ int sscan[8];
 
     const CellDesc cd = cells[blockIdx.x];
     const LevelGeom L = G.lv[cd.level];
@@ -263,87 +228,155 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
         if (tid == 0) cell_cnt[out_cell] = 0;
         return;
     }
-    for (int i = tid; i < sw * sh; i += 256) {
-        int y = i / sw, x = i - y * sw;
-        simg[y * kSubStride + x] = roi[(size_t)(cd.y0 + y) * L.pitch + cd.x0 + x];
+    // LDS column of sub-image x: col = x + a + 4 (4-byte left margin, a = misalignment of x0)
+    const int a = cd.x0 & 3;
+    const int gxb = cd.x0 - a;                          // dword-aligned global column of LDS col 4
+    const int ndw = (a + sw + 3) >> 2;                  // dwords per staged row
+    for (int i = tid; i < sh * kFStrideW; i += 256) {
+        int y = i / kFStrideW, wx = i - y * kFStrideW;
+        uint32_t v = 0;
+        if (wx >= 1 && wx <= ndw)
+            v = *reinterpret_cast<const uint32_t *>(roi + (size_t)(cd.y0 + y) * L.pitch + gxb + 4 * (wx - 1));
+        simg[i] = v;
     }
-    for (int i = tid; i < (dh + 2) * kScoreStride; i += 256) sscore[i] = 0;
+    for (int i = tid; i < (dh + 2) * kFStrideW; i += 256) sscore[i] = 0;
     __syncthreads();
 
-    const int npix = dw * dh;
+    // column groups: group g covers LDS cols 4g..4g+3; valid centre cols [c_lo, c_hi)
+    const int c_lo = a + 4 + 3, c_hi = c_lo + dw;
+    const int g_lo = c_lo >> 2, g_hi = (c_hi - 1) >> 2;
+    const int ngrp = g_hi - g_lo + 1;                   // <= 17
+    const int nwork = ngrp * dh;                        // (row, group) work items, row-major
+    const int magic = ((1 << 20) + ngrp - 1) / ngrp;    // exact floor(i/ngrp) for i < 4096
     const int tmin = G.min_th;
-    for (int p = tid; p < npix; p += 256) {
-        int y = p / dw, x = p - y * dw;
-        const uint8_t *c = &simg[(y + 3) * kSubStride + x + 3];
-        const int v = c[0];
-        const int hi = v + tmin, lo = v - tmin;
-        uint32_t mb = 0, md = 0;
-        int ring[16];
-        ring[0] = c[3 * kSubStride];       ring[1] = c[3 * kSubStride + 1];
-        ring[2] = c[2 * kSubStride + 2];   ring[3] = c[kSubStride + 3];
-        ring[4] = c[3];                    ring[5] = c[-kSubStride + 3];
-        ring[6] = c[-2 * kSubStride + 2];  ring[7] = c[-3 * kSubStride + 1];
-        ring[8] = c[-3 * kSubStride];      ring[9] = c[-3 * kSubStride - 1];
-        ring[10] = c[-2 * kSubStride - 2]; ring[11] = c[-kSubStride - 3];
-        ring[12] = c[-3];                  ring[13] = c[kSubStride - 3];
-        ring[14] = c[2 * kSubStride - 2];  ring[15] = c[3 * kSubStride - 1];
+
+    // ---- scores ----
+    for (int it = tid; it < nwork; it += 256) {
+        const int y = (it * magic) >> 20;               // detection row; sub-image row y+3
+        const int g = g_lo + it - y * ngrp;
+        {
+            uint32_t w[7][3];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            mb |= (uint32_t)(ring[k] > hi) << k;
-            md |= (uint32_t)(ring[k] < lo) << k;
-        }
-        if (has_arc9(mb) || has_arc9(md)) {
-            int s = fast_score(c, v);
-            sscore[(y + 1) * kScoreStride + x + 1] = (uint8_t)min(max(s, 0), 255);
+            for (int r = 0; r < 7; ++r) {
+                const uint32_t *p = &simg[(y + r) * kFStrideW + g - 1];
+                w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = p[2];
+            }
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 4 * g + j;
+                const int v = ORB_BYTE(w[3][0], w[3][1], w[3][2], 4 + j);
+                // compass pre-test (pixels 0,4,8,12): an arc of 9 holds one of each opposite pair
+                const int p0 = ORB_BYTE(w[6][0], w[6][1], w[6][2], 4 + j);
+                const int p8 = ORB_BYTE(w[0][0], w[0][1], w[0][2], 4 + j);
+                const int p4 = ORB_BYTE(w[3][0], w[3][1], w[3][2], 7 + j);
+                const int p12 = ORB_BYTE(w[3][0], w[3][1], w[3][2], 1 + j);
+                const int hi = v + tmin, lo = v - tmin;
+                const bool pre = (((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi))) |
+                                 (((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo)));
+                int sc = 0;
+                if (pre && col >= c_lo && col < c_hi) {
+                    int d[16];
+                    d[0] = v - p0;
+                    d[1] = v - ORB_BYTE(w[6][0], w[6][1], w[6][2], 5 + j);
+                    d[2] = v - ORB_BYTE(w[5][0], w[5][1], w[5][2], 6 + j);
+                    d[3] = v - ORB_BYTE(w[4][0], w[4][1], w[4][2], 7 + j);
+                    d[4] = v - p4;
+                    d[5] = v - ORB_BYTE(w[2][0], w[2][1], w[2][2], 7 + j);
+                    d[6] = v - ORB_BYTE(w[1][0], w[1][1], w[1][2], 6 + j);
+                    d[7] = v - ORB_BYTE(w[0][0], w[0][1], w[0][2], 5 + j);
+                    d[8] = v - p8;
+                    d[9] = v - ORB_BYTE(w[0][0], w[0][1], w[0][2], 3 + j);
+                    d[10] = v - ORB_BYTE(w[1][0], w[1][1], w[1][2], 2 + j);
+                    d[11] = v - ORB_BYTE(w[2][0], w[2][1], w[2][2], 1 + j);
+                    d[12] = v - p12;
+                    d[13] = v - ORB_BYTE(w[4][0], w[4][1], w[4][2], 1 + j);
+                    d[14] = v - ORB_BYTE(w[5][0], w[5][1], w[5][2], 2 + j);
+                    d[15] = v - ORB_BYTE(w[6][0], w[6][1], w[6][2], 3 + j);
+                    int m3[16], M3[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        m3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+                        M3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+                    }
+                    int dark = -1000, brightneg = 1000;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        dark = max(dark, min3i(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]));
+                        brightneg = min(brightneg, max3i(M3[k], M3[(k + 3) & 15], M3[(k + 6) & 15]));
+                    }
+                    sc = max(dark, -brightneg) - 1;
+                    sc = sc >= tmin ? min(sc, 255) : 0;   // corner at minTh <=> S >= minTh
+                }
+                packed |= (uint32_t)sc << (8 * j);
+            }
+            sscore[(y + 1) * kFStrideW + g] = packed;
         }
     }
     __syncthreads();
 
-    // NMS at iniTh; count survivors
+    // ---- NMS: strict local maximum among the 8 neighbours (threshold independent) ----
+    auto nms = [&](int y, int g, uint32_t &scores) -> uint32_t {
+        uint32_t s[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint32_t *p = &sscore[(y + r) * kFStrideW + g - 1];
+            s[r][0] = p[0]; s[r][1] = p[1]; s[r][2] = p[2];
+        }
+        scores = s[1][1];
+        uint32_t lm = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int v = ORB_BYTE(s[1][0], s[1][1], s[1][2], 4 + j);
+            bool k = v > ORB_BYTE(s[1][0], s[1][1], s[1][2], 3 + j) && v > ORB_BYTE(s[1][0], s[1][1], s[1][2], 5 + j);
+#pragma unroll
+            for (int o = 3; o <= 5; ++o)
+                k = k && v > ORB_BYTE(s[0][0], s[0][1], s[0][2], o + j) && v > ORB_BYTE(s[2][0], s[2][1], s[2][2], o + j);
+            lm |= (uint32_t)k << j;
+        }
+        return lm;
+    };
     int th = G.ini_th;
     int cnt = 0;
-    for (int p = tid; p < npix; p += 256) {
-        int y = p / dw, x = p - y * dw;
-        const uint8_t *s = &sscore[(y + 1) * kScoreStride + x + 1];
-        int v = s[0];
-        bool keep = v >= th && v > s[-1] && v > s[1] && v > s[-kScoreStride - 1] && v > s[-kScoreStride] &&
-                    v > s[-kScoreStride + 1] && v > s[kScoreStride - 1] && v > s[kScoreStride] && v > s[kScoreStride + 1];
-        cnt += keep;
+    for (int it = tid; it < nwork; it += 256) {
+        const int y = (it * magic) >> 20;
+        const int g = g_lo + it - y * ngrp;
+        uint32_t sc;
+        uint32_t lm = nms(y, g, sc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cnt += ((lm >> j) & 1) && (int)((sc >> (8 * j)) & 0xff) >= th;
     }
-    int any = __syncthreads_or(cnt);
-    if (!any) th = G.min_th;
-    if (tid == 0) sbase = 0;
-    __syncthreads();
+    if (!__syncthreads_or(cnt)) th = G.min_th;
 
+    // ---- ordered emission (row-major = thread-linear order inside a pass) ----
     uint32_t *out = cell_kp + out_cell * G.slot_cap;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int start = 0; start < npix; start += 256) {
-        int p = start + tid;
-        bool keep = false;
-        int x = 0, y = 0, v = 0;
-        if (p < npix) {
-            y = p / dw; x = p - y * dw;
-            const uint8_t *s = &sscore[(y + 1) * kScoreStride + x + 1];
-            v = s[0];
-            keep = v >= th && v > s[-1] && v > s[1] && v > s[-kScoreStride - 1] && v > s[-kScoreStride] &&
-                   v > s[-kScoreStride + 1] && v > s[kScoreStride - 1] && v > s[kScoreStride] && v > s[kScoreStride + 1];
+    int base = 0;
+    for (int it0 = 0; it0 < nwork; it0 += 256) {
+        const int it = it0 + tid;
+        const int y = (it * magic) >> 20;
+        const int g = g_lo + it - y * ngrp;
+        uint32_t sc = 0, keep = 0;
+        if (it < nwork) {
+            uint32_t lm = nms(y, g, sc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (((lm >> j) & 1) && (int)((sc >> (8 * j)) & 0xff) >= th) keep |= 1u << j;
         }
-        unsigned long long bal = __ballot(keep);
-        if (lane == 0) swave[wave] = __popcll(bal);
-        __syncthreads();
-        int off = sbase;
-        for (int w = 0; w < wave; ++w) off += swave[w];
-        off += __popcll(bal & ((1ull << lane) - 1ull));
-        if (keep && off < G.slot_cap) {
-            // keypoint relative to (minBorderX, minBorderY): FAST coords (x+3,y+3) + cell offset
-            uint32_t kx = (uint32_t)(x + 3 + cd.offx), ky = (uint32_t)(y + 3 + cd.offy);
-            out[off] = kx | (ky << 12) | ((uint32_t)v << 24);
-        }
-        __syncthreads();
-        if (tid == 0) sbase += swave[0] + swave[1] + swave[2] + swave[3];
-        __syncthreads();
+        int tot;
+        int off = base + block_excl_scan256(__popc(keep), sscan, &tot);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((keep >> j) & 1) {
+                if (off < G.slot_cap) {
+                    // keypoint relative to (minBorderX, minBorderY): FAST coords + cell offset
+                    uint32_t kx = (uint32_t)(4 * g + j - 4 - a + cd.offx), ky = (uint32_t)(y + 3 + cd.offy);
+                    out[off] = kx | (ky << 12) | (((sc >> (8 * j)) & 0xffu) << 24);
+                }
+                ++off;
+            }
+        base += tot;
     }
-    if (tid == 0) cell_cnt[out_cell] = min(sbase, G.slot_cap);
+    if (tid == 0) cell_cnt[out_cell] = min(base, G.slot_cap);
 }
 
 // ---------------------------------------------------------------------------
@@ -622,46 +655,92 @@ __global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict
 }
 
 // ---------------------------------------------------------------------------
-// K6: GaussianBlur(7x7, sigma 2, REFLECT_101) per level (:1085-1086).  Separable
-// integer kernel through LDS: a 64x32 output tile loads a 70x38 halo tile from the
-// padded plane (the 19-px REFLECT_101 frame supplies the border), row pass to
-// uint16 (<= 255*257), column pass (sum + 2^15) >> 16, saturated.
+// K6: GaussianBlur(7x7, sigma 2, REFLECT_101) per level (:1085-1086).  Separable integer
+// kernel through LDS.  A 64x58 output tile stages 64 rows x 72 bytes of the padded plane with
+// aligned dword loads (the 19-px REFLECT_101 frame supplies the border).  Row pass: one thread
+// = 4 pixels x 2 rows, two v_dot4_u32_u8 per pixel on byte-aligned windows; the uint16 row sums
+// (<= 255*257) of rows 2r,2r+1 are stored interleaved in one dword so that the column pass is
+// three v_dot2_u32_u16 + one multiply per pixel; (sum + 2^15) >> 16, saturated; dword stores.
 // ---------------------------------------------------------------------------
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+constexpr int kBIn = kBlurTH + 6;   // staged input rows (64)
+constexpr int kBInW = 18;           // staged dwords per row: tile bytes x0-4 .. x0+67
+
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b), c, false);
+}
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                               PyrGeom G, const TileDesc *__restrict__ tiles, BlurW W)
 {
-    __shared__ uint8_t sin[(kBlurTH + 6) * (kBlurTW + 8)];
-    __shared__ unsigned short srow[(kBlurTH + 6) * kBlurTW];
+    __shared__ uint32_t sin[kBIn * kBInW];
+    __shared__ uint4 srow[(kBIn / 2) * (kBlurTW / 4)];   // [pair-row][group]: 4 px x (row 2r | row 2r+1 << 16)
     const TileDesc t = tiles[blockIdx.x];
     const LevelGeom L = G.lv[t.level];
     const size_t fo = (size_t)blockIdx.y * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
     const uint8_t *roi = pyr + fo;
     uint8_t *out = blur + fo;
     const int x0 = t.tx * kBlurTW, y0 = t.ty * kBlurTH;
+    const int rows = min(kBlurTH, L.h - y0);
+    const int nin = rows + 6, npair = (nin + 1) >> 1;
     const int tid = threadIdx.x;
-    constexpr int SW = kBlurTW + 8;
-    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += 256) {
-        int y = i / (kBlurTW + 6), x = i - y * (kBlurTW + 6);
-        int gx = min(x0 + x - 3, L.w + kEdge - 1), gy = min(y0 + y - 3, L.h + kEdge - 1);
-        sin[y * SW + x] = roi[(ptrdiff_t)gy * L.pitch + gx];
+    const int gxmax = (L.w + 12) & ~3;
+    for (int i = tid; i < nin * kBInW; i += 256) {
+        const int r = i / kBInW, c = i - r * kBInW;
+        const int gy = min(y0 - 3 + r, L.h + kEdge - 1), gx = min(x0 - 4 + 4 * c, gxmax);
+        sin[i] = *reinterpret_cast<const uint32_t *>(roi + (ptrdiff_t)gy * L.pitch + gx);
     }
+    const uint32_t wlo = (uint32_t)W.w[0] | ((uint32_t)W.w[1] << 8) | ((uint32_t)W.w[2] << 16) | ((uint32_t)W.w[3] << 24);
+    const uint32_t whi = (uint32_t)W.w[4] | ((uint32_t)W.w[5] << 8) | ((uint32_t)W.w[6] << 16);
     __syncthreads();
-    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
-        int y = i / kBlurTW, x = i - y * kBlurTW;
-        const uint8_t *p = &sin[y * SW + x];
-        int acc = W.w[0] * p[0] + W.w[1] * p[1] + W.w[2] * p[2] + W.w[3] * p[3] + W.w[4] * p[4] + W.w[5] * p[5] + W.w[6] * p[6];
-        srow[i] = (unsigned short)acc;
-    }
-    __syncthreads();
-    for (int i = tid; i < kBlurTH * kBlurTW; i += 256) {
-        int y = i / kBlurTW, x = i - y * kBlurTW;
-        if (x0 + x < L.w && y0 + y < L.h) {
-            const unsigned short *p = &srow[y * kBlurTW + x];
-            int acc = W.w[0] * p[0] + W.w[1] * p[kBlurTW] + W.w[2] * p[2 * kBlurTW] + W.w[3] * p[3 * kBlurTW] +
-                      W.w[4] * p[4 * kBlurTW] + W.w[5] * p[5 * kBlurTW] + W.w[6] * p[6 * kBlurTW];
-            out[(size_t)(y0 + y) * L.pitch + x0 + x] = (uint8_t)min((acc + 32768) >> 16, 255);
+    // row pass: item = (pair-row, 4-px group)
+    for (int it = tid; it < npair * 16; it += 256) {
+        const int pr = it >> 4, g = it & 15;
+        uint32_t s[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t *p = &sin[min(2 * pr + h, nin - 1) * kBInW + g];
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            // output j needs tile bytes 4g+1+j .. 4g+7+j
+            s[h][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), wlo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), whi, 0, false), false);
+            s[h][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), wlo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), whi, 0, false), false);
+            s[h][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), wlo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), whi, 0, false), false);
+            s[h][3] = __builtin_amdgcn_udot4(d1, wlo, __builtin_amdgcn_udot4(d2, whi, 0, false), false);
         }
+        srow[it] = make_uint4(s[0][0] | (s[1][0] << 16), s[0][1] | (s[1][1] << 16), s[0][2] | (s[1][2] << 16),
+                              s[0][3] | (s[1][3] << 16));
+    }
+    __syncthreads();
+    // column pass: item = (output row, group); rows are permuted inside blocks of 8 so that the four
+    // rows of a wavefront share their parity (no divergence between the even/odd pairings)
+    const uint32_t w01 = (uint32_t)W.w[0] | ((uint32_t)W.w[1] << 16), w23 = (uint32_t)W.w[2] | ((uint32_t)W.w[3] << 16),
+                   w45 = (uint32_t)W.w[4] | ((uint32_t)W.w[5] << 16), w12 = (uint32_t)W.w[1] | ((uint32_t)W.w[2] << 16),
+                   w34 = (uint32_t)W.w[3] | ((uint32_t)W.w[4] << 16), w56 = (uint32_t)W.w[5] | ((uint32_t)W.w[6] << 16);
+    const int nrows8 = (rows + 7) & ~7;
+    for (int it = tid; it < nrows8 * 16; it += 256) {
+        const int q = it >> 4, g = it & 15;
+        const int y = (q & ~7) | ((q & 3) << 1) | ((q >> 2) & 1);
+        if (y >= rows || x0 + 4 * g >= L.w) continue;
+        const int p = y >> 1;
+        const uint4 P0 = srow[p * 16 + g], P1 = srow[(p + 1) * 16 + g], P2 = srow[(p + 2) * 16 + g], P3 = srow[(p + 3) * 16 + g];
+        const uint32_t a0[4] = {P0.x, P0.y, P0.z, P0.w}, a1[4] = {P1.x, P1.y, P1.z, P1.w},
+                       a2[4] = {P2.x, P2.y, P2.z, P2.w}, a3[4] = {P3.x, P3.y, P3.z, P3.w};
+        uint32_t res = 0;
+        if ((y & 1) == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t acc = udot2(a0[j], w01, udot2(a1[j], w23, udot2(a2[j], w45, (a3[j] & 0xffffu) * (uint32_t)W.w[6])));
+                res |= min((acc + 32768u) >> 16, 255u) << (8 * j);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t acc = udot2(a1[j], w12, udot2(a2[j], w34, udot2(a3[j], w56, (a0[j] >> 16) * (uint32_t)W.w[0])));
+                res |= min((acc + 32768u) >> 16, 255u) << (8 * j);
+            }
+        }
+        *reinterpret_cast<uint32_t *>(out + (size_t)(y0 + y) * L.pitch + x0 + 4 * g) = res;
     }
 }
 
@@ -1097,7 +1176,7 @@ int orbhip_extractor_set_blur_kernel(orbhip_extractor *e, const int32_t w[7])
 {
     if (!e || !w) return ORBHIP_E_ARG;
     int s = 0;
-    for (int i = 0; i < 7; ++i) { if (w[i] < 0 || w[i] > 256) return ORBHIP_E_ARG; s += w[i]; }
+    for (int i = 0; i < 7; ++i) { if (w[i] < 0 || w[i] > 255) return ORBHIP_E_ARG; s += w[i]; }
     if (s > 257) { set_error("blur weights sum %d > 257 overflows the uint16 row pass", s); return ORBHIP_E_ARG; }
     for (int i = 0; i < 7; ++i) e->blurw.w[i] = w[i];
     return ORBHIP_OK;

@@ -7,7 +7,7 @@
 namespace orbhip {
 struct BlurW { int w[7]; };
 struct TileDesc { short level, tx, ty, pad; };
-constexpr int kBlurTW = 64, kBlurTH = 32;
+constexpr int kBlurTW = 64, kBlurTH = 58;
 struct DiscTab { signed char u[768], v[768]; };  // 749 used
 }  // namespace orbhip
 

@@ -136,9 +136,10 @@ def test_blur_kernel_is_a_data_table(mods):
     pkg, O = mods
     ext = pkg.ORBextractor(300, 1.2, 4, 20, 7)
     img = synth_frame(2, 320, 240)
-    ext.set_blur_kernel([0, 0, 0, 256, 0, 0, 0])     # identity: blurred level == level
+    ext.set_blur_kernel([0, 0, 0, 255, 0, 0, 0])     # near-identity (255/256)^2: <= 2 grey levels off
     ext(img)
-    assert np.array_equal(ext.blurred_level(0), ext.image_pyramid(0))
+    d = np.abs(ext.blurred_level(0).astype(int) - ext.image_pyramid(0).astype(int))
+    assert d.max() <= 2
     ext.set_blur_kernel([18, 34, 49, 55, 49, 34, 18])
     ext(img)
     assert not np.array_equal(ext.blurred_level(0), ext.image_pyramid(0))
