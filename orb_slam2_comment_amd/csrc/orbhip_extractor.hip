@@ -188,15 +188,19 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
 }
 
 // ---------------------------------------------------------------------------
-// K2+K3: FAST-9/16 + NMS, one workgroup per reference cell (= one cv::FAST call,
-// ORBextractor.cc:789-829).  The (wCell+6)x(hCell+6) sub-image is staged in LDS with
-// aligned dword loads; every thread owns 4 horizontally adjacent pixels (one LDS dword
-// column group) and reads its 7x12-byte neighbourhood as 21 dwords.  The
-// threshold-independent score S = max(dark,bright)-1 (cornerScore<16>) is computed with
-// min3/max3 networks for pixels that pass the compass pre-test at minThFAST (others
-// hold 0); NMS runs at iniThFAST and falls back to minThFAST when the cell keeps nothing
-// (:812-816).  Neighbours outside the detection rectangle count as 0, exactly like the
-// reference's zero-initialised score rows.  Survivors are emitted in row-major order.
+// K2+K3: FAST-9/16 + NMS, one WAVEFRONT per reference cell (= one cv::FAST call,
+// ORBextractor.cc:789-829); 64-thread workgroups, so every hand-off below is wave-local.
+//  1. the (wCell+6)x(hCell+6) sub-image is staged in LDS with aligned dword loads;
+//  2. dense compass pre-test at minThFAST (ring pixels 0,4,8,12: an arc of 9 holds at least one
+//     pixel of every opposite pair), 4 px per lane; survivors (~8 % of pixels) are compacted
+//     into an LDS list with wave ballots;
+//  3. the threshold-independent score S = max(dark,bright)-1 (cornerScore<16>) is computed
+//     only for survivors, at full lane occupancy, with min3/max3 networks; pixels with
+//     S >= minThFAST (corners at minTh) go to the score map and a second list;
+//  4. NMS (strict maximum over the 8 neighbours; outside the detection rectangle = 0, like the
+//     reference's zero-initialised score rows) runs over that list only;
+//  5. threshold selection iniThFAST / fallback minThFAST (:812-816) and row-major ordering
+//     by rank counting over the (few) survivors.
 // ---------------------------------------------------------------------------
 constexpr int kSubMax = 72;              // max (wCell+6), (hCell+6)
 constexpr int kFStride = 84;             // LDS row stride in bytes (21 dwords): 4 margin + <=75 + spare
@@ -204,42 +208,47 @@ constexpr int kFStrideW = kFStride / 4;
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
-// byte `o` (0..11) of the 12-byte window {w0,w1,w2}
-#define ORB_BYTE(w0, w1, w2, o) ((int)((((o) < 4 ? (w0) : (o) < 8 ? (w1) : (w2)) >> (8 * ((o) & 3))) & 0xffu))
-
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, PyrGeom G,
-                                                    const CellDesc *__restrict__ cells,
-                                                    int *__restrict__ cell_cnt,
-                                                    uint32_t *__restrict__ cell_kp)
+__device__ __forceinline__ int lane_prefix(unsigned long long m)
 {
-    __shared__ uint32_t simg[kSubMax * kFStrideW];
-    __shared__ uint32_t sscore[(kSubMax + 2) * kFStrideW];
-    __shared__ int sscan[8];
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+}
+
+__global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, PyrGeom G,
+                                                   const CellDesc *__restrict__ cells,
+                                                   int *__restrict__ cell_cnt,
+                                                   uint32_t *__restrict__ cell_kp, int lds_img_words,
+                                                   int lds_score_words, int lds_list_words)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t *simg = lds;                                   // staged sub-image
+    uint32_t *sscore = lds + lds_img_words;                 // score map, 1-px zero halo rows
+    unsigned short *slist = reinterpret_cast<unsigned short *>(sscore + lds_score_words);  // (y<<7)|col
+    uint32_t *sfinal = sscore + lds_score_words + lds_list_words;                          // NMS survivors
 
     const CellDesc cd = cells[blockIdx.x];
     const LevelGeom L = G.lv[cd.level];
     const uint8_t *roi = pyr + (size_t)blockIdx.y * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
     const int sw = cd.x1 - cd.x0, sh = cd.y1 - cd.y0;  // sub-image size
     const int dw = sw - 6, dh = sh - 6;                // detection rectangle
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const size_t out_cell = (size_t)blockIdx.y * G.ncells_total + blockIdx.x;
 
     if (dw <= 0 || dh <= 0) {  // cv::FAST on an image narrower than 7 px finds nothing
-        if (tid == 0) cell_cnt[out_cell] = 0;
+        if (lane == 0) cell_cnt[out_cell] = 0;
         return;
     }
     // LDS column of sub-image x: col = x + a + 4 (4-byte left margin, a = misalignment of x0)
     const int a = cd.x0 & 3;
     const int gxb = cd.x0 - a;                          // dword-aligned global column of LDS col 4
     const int ndw = (a + sw + 3) >> 2;                  // dwords per staged row
-    for (int i = tid; i < sh * kFStrideW; i += 256) {
+    for (int i = lane; i < sh * kFStrideW; i += 64) {
         int y = i / kFStrideW, wx = i - y * kFStrideW;
         uint32_t v = 0;
         if (wx >= 1 && wx <= ndw)
             v = *reinterpret_cast<const uint32_t *>(roi + (size_t)(cd.y0 + y) * L.pitch + gxb + 4 * (wx - 1));
         simg[i] = v;
     }
-    for (int i = tid; i < (dh + 2) * kFStrideW; i += 256) sscore[i] = 0;
+    for (int i = lane; i < (dh + 2) * kFStrideW; i += 64) sscore[i] = 0;
     __syncthreads();
 
     // column groups: group g covers LDS cols 4g..4g+3; valid centre cols [c_lo, c_hi)
@@ -250,133 +259,131 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const int magic = ((1 << 20) + ngrp - 1) / ngrp;    // exact floor(i/ngrp) for i < 4096
     const int tmin = G.min_th;
 
-    // ---- scores ----
-    for (int it = tid; it < nwork; it += 256) {
+    // ---- 2. dense pre-test, survivors -> slist ----
+    int nsurv = 0;
+    for (int it0 = 0; it0 < nwork; it0 += 64) {
+        const int it = it0 + lane;
         const int y = (it * magic) >> 20;               // detection row; sub-image row y+3
         const int g = g_lo + it - y * ngrp;
-        {
-            uint32_t w[7][3];
+        uint32_t c0 = 0, c1 = 0, c2 = 0, up = 0, dn = 0;
+        if (it < nwork) {
+            const uint32_t *p = &simg[(y + 3) * kFStrideW + g - 1];
+            c0 = p[0]; c1 = p[1]; c2 = p[2];
+            up = simg[y * kFStrideW + g];
+            dn = simg[(y + 6) * kFStrideW + g];
+        }
+        const unsigned long long win = ((unsigned long long)c1 << 32) | c0;   // bytes 0..7 of the row window
+        const unsigned long long win2 = ((unsigned long long)c2 << 32) | c1;  // bytes 4..11
 #pragma unroll
-            for (int r = 0; r < 7; ++r) {
-                const uint32_t *p = &simg[(y + r) * kFStrideW + g - 1];
-                w[r][0] = p[0]; w[r][1] = p[1]; w[r][2] = p[2];
-            }
-            uint32_t packed = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = 4 * g + j;
-                const int v = ORB_BYTE(w[3][0], w[3][1], w[3][2], 4 + j);
-                // compass pre-test (pixels 0,4,8,12): an arc of 9 holds one of each opposite pair
-                const int p0 = ORB_BYTE(w[6][0], w[6][1], w[6][2], 4 + j);
-                const int p8 = ORB_BYTE(w[0][0], w[0][1], w[0][2], 4 + j);
-                const int p4 = ORB_BYTE(w[3][0], w[3][1], w[3][2], 7 + j);
-                const int p12 = ORB_BYTE(w[3][0], w[3][1], w[3][2], 1 + j);
-                const int hi = v + tmin, lo = v - tmin;
-                const bool pre = (((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi))) |
-                                 (((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo)));
-                int sc = 0;
-                if (pre && col >= c_lo && col < c_hi) {
-                    int d[16];
-                    d[0] = v - p0;
-                    d[1] = v - ORB_BYTE(w[6][0], w[6][1], w[6][2], 5 + j);
-                    d[2] = v - ORB_BYTE(w[5][0], w[5][1], w[5][2], 6 + j);
-                    d[3] = v - ORB_BYTE(w[4][0], w[4][1], w[4][2], 7 + j);
-                    d[4] = v - p4;
-                    d[5] = v - ORB_BYTE(w[2][0], w[2][1], w[2][2], 7 + j);
-                    d[6] = v - ORB_BYTE(w[1][0], w[1][1], w[1][2], 6 + j);
-                    d[7] = v - ORB_BYTE(w[0][0], w[0][1], w[0][2], 5 + j);
-                    d[8] = v - p8;
-                    d[9] = v - ORB_BYTE(w[0][0], w[0][1], w[0][2], 3 + j);
-                    d[10] = v - ORB_BYTE(w[1][0], w[1][1], w[1][2], 2 + j);
-                    d[11] = v - ORB_BYTE(w[2][0], w[2][1], w[2][2], 1 + j);
-                    d[12] = v - p12;
-                    d[13] = v - ORB_BYTE(w[4][0], w[4][1], w[4][2], 1 + j);
-                    d[14] = v - ORB_BYTE(w[5][0], w[5][1], w[5][2], 2 + j);
-                    d[15] = v - ORB_BYTE(w[6][0], w[6][1], w[6][2], 3 + j);
-                    int m3[16], M3[16];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        m3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-                        M3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-                    }
-                    int dark = -1000, brightneg = 1000;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        dark = max(dark, min3i(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]));
-                        brightneg = min(brightneg, max3i(M3[k], M3[(k + 3) & 15], M3[(k + 6) & 15]));
-                    }
-                    sc = max(dark, -brightneg) - 1;
-                    sc = sc >= tmin ? min(sc, 255) : 0;   // corner at minTh <=> S >= minTh
-                }
-                packed |= (uint32_t)sc << (8 * j);
-            }
-            sscore[(y + 1) * kFStrideW + g] = packed;
+        for (int j = 0; j < 4; ++j) {
+            const int col = 4 * g + j;
+            const int v = (int)((c1 >> (8 * j)) & 0xff);
+            const int p0 = (int)((dn >> (8 * j)) & 0xff), p8 = (int)((up >> (8 * j)) & 0xff);
+            const int p4 = (int)((win2 >> (8 * (3 + j))) & 0xff);    // byte 7+j
+            const int p12 = (int)((win >> (8 * (1 + j))) & 0xff);    // byte 1+j
+            const int hi = v + tmin, lo = v - tmin;
+            const bool pre = it < nwork && col >= c_lo && col < c_hi &&
+                             ((((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi))) |
+                              (((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo))));
+            const unsigned long long m = __ballot(pre);
+            if (pre) slist[nsurv + lane_prefix(m)] = (unsigned short)((y << 7) | col);
+            nsurv += __popcll(m);
         }
     }
     __syncthreads();
 
-    // ---- NMS: strict local maximum among the 8 neighbours (threshold independent) ----
-    auto nms = [&](int y, int g, uint32_t &scores) -> uint32_t {
-        uint32_t s[3][3];
+    // ---- 3. score of the survivors; corners at minTh -> score map + slist (in place) ----
+    const uint8_t *img8 = reinterpret_cast<const uint8_t *>(simg);
+    uint8_t *score8 = reinterpret_cast<uint8_t *>(sscore);
+    int ncorn = 0;
+    for (int i0 = 0; i0 < nsurv; i0 += 64) {
+        const int i = i0 + lane;
+        bool isc = false;
+        unsigned short e = 0;
+        if (i < nsurv) {
+            e = slist[i];
+            const int y = e >> 7, col = e & 127;
+            const uint8_t *c = img8 + (y + 3) * kFStride + col;
+            const int v = c[0];
+            int d[16];
+            d[0] = v - c[3 * kFStride];       d[1] = v - c[3 * kFStride + 1];
+            d[2] = v - c[2 * kFStride + 2];   d[3] = v - c[kFStride + 3];
+            d[4] = v - c[3];                  d[5] = v - c[-kFStride + 3];
+            d[6] = v - c[-2 * kFStride + 2];  d[7] = v - c[-3 * kFStride + 1];
+            d[8] = v - c[-3 * kFStride];      d[9] = v - c[-3 * kFStride - 1];
+            d[10] = v - c[-2 * kFStride - 2]; d[11] = v - c[-kFStride - 3];
+            d[12] = v - c[-3];                d[13] = v - c[kFStride - 3];
+            d[14] = v - c[2 * kFStride - 2];  d[15] = v - c[3 * kFStride - 1];
+            int m3[16], M3[16];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const uint32_t *p = &sscore[(y + r) * kFStrideW + g - 1];
-            s[r][0] = p[0]; s[r][1] = p[1]; s[r][2] = p[2];
-        }
-        scores = s[1][1];
-        uint32_t lm = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int v = ORB_BYTE(s[1][0], s[1][1], s[1][2], 4 + j);
-            bool k = v > ORB_BYTE(s[1][0], s[1][1], s[1][2], 3 + j) && v > ORB_BYTE(s[1][0], s[1][1], s[1][2], 5 + j);
-#pragma unroll
-            for (int o = 3; o <= 5; ++o)
-                k = k && v > ORB_BYTE(s[0][0], s[0][1], s[0][2], o + j) && v > ORB_BYTE(s[2][0], s[2][1], s[2][2], o + j);
-            lm |= (uint32_t)k << j;
-        }
-        return lm;
-    };
-    int th = G.ini_th;
-    int cnt = 0;
-    for (int it = tid; it < nwork; it += 256) {
-        const int y = (it * magic) >> 20;
-        const int g = g_lo + it - y * ngrp;
-        uint32_t sc;
-        uint32_t lm = nms(y, g, sc);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cnt += ((lm >> j) & 1) && (int)((sc >> (8 * j)) & 0xff) >= th;
-    }
-    if (!__syncthreads_or(cnt)) th = G.min_th;
-
-    // ---- ordered emission (row-major = thread-linear order inside a pass) ----
-    uint32_t *out = cell_kp + out_cell * G.slot_cap;
-    int base = 0;
-    for (int it0 = 0; it0 < nwork; it0 += 256) {
-        const int it = it0 + tid;
-        const int y = (it * magic) >> 20;
-        const int g = g_lo + it - y * ngrp;
-        uint32_t sc = 0, keep = 0;
-        if (it < nwork) {
-            uint32_t lm = nms(y, g, sc);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (((lm >> j) & 1) && (int)((sc >> (8 * j)) & 0xff) >= th) keep |= 1u << j;
-        }
-        int tot;
-        int off = base + block_excl_scan256(__popc(keep), sscan, &tot);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((keep >> j) & 1) {
-                if (off < G.slot_cap) {
-                    // keypoint relative to (minBorderX, minBorderY): FAST coords + cell offset
-                    uint32_t kx = (uint32_t)(4 * g + j - 4 - a + cd.offx), ky = (uint32_t)(y + 3 + cd.offy);
-                    out[off] = kx | (ky << 12) | (((sc >> (8 * j)) & 0xffu) << 24);
-                }
-                ++off;
+            for (int k = 0; k < 16; ++k) {
+                m3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+                M3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
             }
-        base += tot;
+            int mn9[16], mx9[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                mn9[k] = min3i(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+                mx9[k] = max3i(M3[k], M3[(k + 3) & 15], M3[(k + 6) & 15]);
+            }
+            int dark = max3i(max3i(mn9[0], mn9[1], mn9[2]), max3i(mn9[3], mn9[4], mn9[5]), max3i(mn9[6], mn9[7], mn9[8]));
+            dark = max3i(dark, max3i(mn9[9], mn9[10], mn9[11]), max3i(mn9[12], mn9[13], max(mn9[14], mn9[15])));
+            int brn = min3i(min3i(mx9[0], mx9[1], mx9[2]), min3i(mx9[3], mx9[4], mx9[5]), min3i(mx9[6], mx9[7], mx9[8]));
+            brn = min3i(brn, min3i(mx9[9], mx9[10], mx9[11]), min3i(mx9[12], mx9[13], min(mx9[14], mx9[15])));
+            const int sc = max(dark, -brn) - 1;       // cornerScore; corner at minTh <=> S >= minTh
+            isc = sc >= tmin;
+            if (isc) score8[(y + 1) * kFStride + col] = (uint8_t)min(sc, 255);
+        }
+        const unsigned long long m = __ballot(isc);
+        if (isc) slist[ncorn + lane_prefix(m)] = e;     // write index <= read index: in place is safe
+        ncorn += __popcll(m);
     }
-    if (tid == 0) cell_cnt[out_cell] = min(base, G.slot_cap);
+    __syncthreads();
+
+    // ---- 4. NMS over the corner list ----
+    int nfin = 0, nini = 0;
+    for (int i0 = 0; i0 < ncorn; i0 += 64) {
+        const int i = i0 + lane;
+        bool keep = false;
+        uint32_t key = 0;
+        if (i < ncorn) {
+            const unsigned short e = slist[i];
+            const int y = e >> 7, col = e & 127;
+            const uint8_t *s = score8 + (y + 1) * kFStride + col;
+            const int v = s[0];
+            keep = v > s[-1] && v > s[1] && v > s[-kFStride - 1] && v > s[-kFStride] && v > s[-kFStride + 1] &&
+                   v > s[kFStride - 1] && v > s[kFStride] && v > s[kFStride + 1];
+            key = ((uint32_t)e << 8) | (uint32_t)v;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) sfinal[nfin + lane_prefix(m)] = key;
+        nfin += __popcll(m);
+        nini += __popcll(__ballot(keep && (int)(key & 0xff) >= G.ini_th));
+    }
+    __syncthreads();
+
+    // ---- 5. threshold fallback + row-major order by rank counting ----
+    const int th = nini > 0 ? G.ini_th : G.min_th;
+    uint32_t *out = cell_kp + out_cell * G.slot_cap;
+    int total = 0;
+    for (int i0 = 0; i0 < nfin; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t key = i < nfin ? sfinal[i] : 0;
+        const bool ok = i < nfin && (int)(key & 0xff) >= th;
+        int rank = 0;
+        for (int j = 0; j < nfin; ++j) {
+            const uint32_t kj = sfinal[j];
+            rank += ((int)(kj & 0xff) >= th) && (kj < key);
+        }
+        if (ok && rank < G.slot_cap) {
+            const int y = (int)(key >> 15), col = (int)((key >> 8) & 127);
+            // keypoint relative to (minBorderX, minBorderY): FAST coords + cell offset
+            const uint32_t kx = (uint32_t)(col - 4 - a + cd.offx), ky = (uint32_t)(y + 3 + cd.offy);
+            out[rank] = kx | (ky << 12) | ((key & 0xffu) << 24);
+        }
+        total += __popcll(__ballot(ok));
+    }
+    if (lane == 0) cell_cnt[out_cell] = min(total, G.slot_cap);
 }
 
 // ---------------------------------------------------------------------------
@@ -964,6 +971,18 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
                 e->tiles.push_back(t);
             }
     }
+    {   // dynamic LDS carve-up of k_fast_cells from the largest cell of this geometry
+        int msh = 7, mdh = 1, mdw = 1;
+        for (const CellDesc &c : e->cells) {
+            msh = std::max(msh, c.y1 - c.y0);
+            mdh = std::max(mdh, c.y1 - c.y0 - 6);
+            mdw = std::max(mdw, c.x1 - c.x0 - 6);
+        }
+        e->fast_lds_words[0] = msh * kFStrideW;
+        e->fast_lds_words[1] = (mdh + 2) * kFStrideW;
+        e->fast_lds_words[2] = (mdw * mdh + 1) / 2 + 1;   // uint16 list: every pixel may pass the pre-test
+        e->fast_lds_words[3] = slot_cap + 64;
+    }
     G.frame_bytes = off;
     G.ncells_total = (int)e->cells.size();
     G.slot_cap = slot_cap;
@@ -1038,8 +1057,10 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     }
     if (prof) hipEventRecord(ev[1], s);
     if (G.ncells_total > 0)
-        hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, batch), dim3(256), 0, s, e->d_pyr, G, e->d_cells,
-                           e->d_cell_cnt, e->d_cell_kp);
+        hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, batch), dim3(64),
+                           (size_t)(e->fast_lds_words[0] + e->fast_lds_words[1] + e->fast_lds_words[2] + e->fast_lds_words[3]) * 4,
+                           s, e->d_pyr, G, e->d_cells, e->d_cell_cnt, e->d_cell_kp, e->fast_lds_words[0],
+                           e->fast_lds_words[1], e->fast_lds_words[2]);
     if (prof) hipEventRecord(ev[2], s);
     if (e->octree_maxn == 512)
         hipLaunchKernelGGL(k_octree<512>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,

@@ -33,6 +33,7 @@ struct orbhip_extractor {
     std::vector<orbhip::CellDesc> cells;
     std::vector<orbhip::TileDesc> tiles;
     int octree_maxn = 512;
+    int fast_lds_words[4] = {0, 0, 0, 0};   // k_fast_cells dynamic LDS: image, score map, list, finals
     orbhip::CellDesc *d_cells = nullptr;
     orbhip::TileDesc *d_tiles = nullptr;
     short *d_tabs = nullptr;
