@@ -62,6 +62,12 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *sh, int *total)
     return base + incl - v;
 }
 
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b), c, false);
+}
+
 // cv::fastAtan2 (degrees in [0,360)); same float operation sequence as the oracle.
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
@@ -149,42 +155,112 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ 
     *reinterpret_cast<uint32_t *>(dst + (size_t)py * L.pitch + pw * 4) = out;
 }
 
-// Resize tables (host-built, OpenCV fixed-point): per destination column
-// {xofs, alpha0, alpha1}, per destination row {sy0, sy1, beta0, beta1} as int16.
+// Resize tables (host-built, OpenCV fixed-point): per destination column sx[x] and the
+// coefficient pair {alpha0, alpha1}, per destination row {sy0, sy1, beta0, beta1}, all int16.
+// Interior groups of 4 destination pixels take the fast path: the <= 6 source bytes of each of
+// the two source rows are fetched with three aligned dword loads, re-aligned with
+// v_alignbyte_b32, and the horizontal taps are v_dot2_u32_u16; groups that touch the
+// REFLECT_101 border recompute the reflected interior pixel byte by byte.
+__device__ __forceinline__ uint32_t resize_px(const uint8_t *S0, const uint8_t *S1, int sx, int a0, int a1, int b0, int b1)
+{
+    // sx+1 may be the first border byte when sx == sw-1; a1 is 0 there.
+    const int r0 = S0[sx] * a0 + S0[sx + 1] * a1;
+    const int r1 = S1[sx] * a0 + S1[sx + 1] * a1;
+    return (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+}
+
+constexpr int kPyrRows = 4;   // destination rows per thread (independent loads in flight)
+
 __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, PyrGeom G, int level,
                                                     const short *__restrict__ tabs)
 {
     const LevelGeom L = G.lv[level];
     const LevelGeom P = G.lv[level - 1];
     const int words = L.pitch >> 2;
+    const int nquads = (L.prows + kPyrRows - 1) / kPyrRows;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= words * L.prows) return;
-    const int py = idx / words, pw = idx - py * words;
+    if (idx >= words * nquads) return;
+    const int rq = idx / words, pw = idx - rq * words;
     uint8_t *frame = pyr + (size_t)blockIdx.y * G.frame_bytes;
     const uint8_t *sroi = frame + P.plane_off + (size_t)kEdge * P.pitch + kPadL;
     uint8_t *dst = frame + L.plane_off;
-    const int dy = reflect101(py - kEdge, L.h);
-    const short *yt = tabs + L.ytab + 4 * dy;
-    const uint8_t *S0 = sroi + (size_t)yt[0] * P.pitch;
-    const uint8_t *S1 = sroi + (size_t)yt[1] * P.pitch;
-    const int b0 = yt[2], b1 = yt[3];
-    uint32_t out = 0;
+    const int x0 = pw * 4 - kPadL;
+    // destination columns of this group after REFLECT_101 (border groups revisit interior columns,
+    // possibly in descending order); pixels beyond the 19-px frame are written as 0
+    int sxk[4];
+    uint32_t alv[4];
+    uint32_t vmask = 0;
+    const bool interior = x0 >= 0 && x0 + 3 < L.w;
+    if (interior) {
+        const short4 sx = *reinterpret_cast<const short4 *>(tabs + L.xtab + x0);
+        const uint4 al = *reinterpret_cast<const uint4 *>(tabs + L.atab + 2 * x0);   // a0 | a1 << 16 per pixel
+        sxk[0] = sx.x; sxk[1] = sx.y; sxk[2] = sx.z; sxk[3] = sx.w;
+        alv[0] = al.x; alv[1] = al.y; alv[2] = al.z; alv[3] = al.w;
+        vmask = 0xffffffffu;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int x = pw * 4 + k - kPadL;
-        uint32_t v = 0;
-        if (x >= -kEdge && x < L.w + kEdge) {
-            const int dx = reflect101(x, L.w);
-            const short *xt = tabs + L.xtab + 3 * dx;
-            const int sx = xt[0], a0 = xt[1], a1 = xt[2];
-            // sx+1 may be the first border byte when sx == sw-1; a1 is 0 there.
-            const int r0 = S0[sx] * a0 + S0[sx + 1] * a1;
-            const int r1 = S1[sx] * a0 + S1[sx + 1] * a1;
-            v = (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + k;
+            if (x >= -kEdge && x < L.w + kEdge) vmask |= 0xffu << (8 * k);
+            const int dx = reflect101(min(max(x, -kEdge), L.w + kEdge - 1), L.w);
+            sxk[k] = tabs[L.xtab + dx];
+            alv[k] = *reinterpret_cast<const uint32_t *>(tabs + L.atab + 2 * dx);
         }
-        out |= v << (8 * k);
     }
-    *reinterpret_cast<uint32_t *>(dst + (size_t)py * L.pitch + pw * 4) = out;
+    const int lo = min(min(sxk[0], sxk[1]), min(sxk[2], sxk[3]));
+    const int hi = max(max(sxk[0], sxk[1]), max(sxk[2], sxk[3]));
+    short4 yt[kPyrRows];
+#pragma unroll
+    for (int r = 0; r < kPyrRows; ++r) {
+        const int py = min(rq * kPyrRows + r, L.prows - 1);
+        yt[r] = *reinterpret_cast<const short4 *>(tabs + L.ytab + 4 * reflect101(py - kEdge, L.h));
+    }
+    uint32_t out[kPyrRows];
+    if (hi - lo <= 6) {   // the 8-byte source window covers all four taps (scale factors <= 2.3)
+        const int base = lo & ~3, o = lo & 3;
+        uint32_t d[kPyrRows][6];
+#pragma unroll
+        for (int r = 0; r < kPyrRows; ++r) {
+            const uint32_t *p0 = reinterpret_cast<const uint32_t *>(sroi + (size_t)yt[r].x * P.pitch + base);
+            const uint32_t *p1 = reinterpret_cast<const uint32_t *>(sroi + (size_t)yt[r].y * P.pitch + base);
+            d[r][0] = p0[0]; d[r][1] = p0[1]; d[r][2] = p0[2];
+            d[r][3] = p1[0]; d[r][4] = p1[1]; d[r][5] = p1[2];
+        }
+        const int rel[4] = {sxk[0] - lo, sxk[1] - lo, sxk[2] - lo, sxk[3] - lo};
+#pragma unroll
+        for (int r = 0; r < kPyrRows; ++r) {
+            const unsigned long long w0 = ((unsigned long long)__builtin_amdgcn_alignbyte(d[r][2], d[r][1], o) << 32) |
+                                          __builtin_amdgcn_alignbyte(d[r][1], d[r][0], o);   // source bytes lo .. lo+7
+            const unsigned long long w1 = ((unsigned long long)__builtin_amdgcn_alignbyte(d[r][5], d[r][4], o) << 32) |
+                                          __builtin_amdgcn_alignbyte(d[r][4], d[r][3], o);
+            const int b0 = yt[r].z, b1 = yt[r].w;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t q0 = (uint32_t)(w0 >> (8 * rel[k])), q1 = (uint32_t)(w1 >> (8 * rel[k]));
+                const uint32_t h0 = udot2((q0 & 0xffu) | ((q0 & 0xff00u) << 8), alv[k], 0);
+                const uint32_t h1 = udot2((q1 & 0xffu) | ((q1 & 0xff00u) << 8), alv[k], 0);
+                const uint32_t v = (uint32_t)((((b0 * (int)(h0 >> 4)) >> 16) + ((b1 * (int)(h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+                acc |= v << (8 * k);
+            }
+            out[r] = acc & vmask;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kPyrRows; ++r) {
+            const uint8_t *S0 = sroi + (size_t)yt[r].x * P.pitch, *S1 = sroi + (size_t)yt[r].y * P.pitch;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                acc |= resize_px(S0, S1, sxk[k], (int)(alv[k] & 0xffff), (int)(alv[k] >> 16), yt[r].z, yt[r].w) << (8 * k);
+            out[r] = acc & vmask;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kPyrRows; ++r) {
+        const int py = rq * kPyrRows + r;
+        if (py < L.prows) *reinterpret_cast<uint32_t *>(dst + (size_t)py * L.pitch + pw * 4) = out[r];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -394,6 +470,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 // key count, newer node first, until the list reaches N), rebuilds the node table in
 // list order (new children reversed in front, survivors behind) and relabels keys.
 // ---------------------------------------------------------------------------
+constexpr int kOctKeysLds = 6144;   // keys held in LDS (36 KB); larger levels use the HBM workspace
+
 template <int MAXN>
 struct OctShared {
     short x0[2][MAXN], x1[2][MAXN], y0[2][MAXN], y1[2][MAXN];
@@ -405,39 +483,25 @@ struct OctShared {
     int cincl[MAXN];           // inclusive scan of child counts in processing order
     int scan[8];
     int vars[8];
+    uint32_t lkeys[kOctKeysLds];        // candidate keys (x | y<<12 | score<<24) when they fit
+    unsigned short lnode[kOctKeysLds];  // owning node of each key
 };
 
-template <int MAXN>
-__global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict__ cell_cnt,
-                                                const uint32_t *__restrict__ cell_kp,
-                                                uint32_t *__restrict__ keys_ws,
-                                                unsigned short *__restrict__ node_ws,
-                                                uint32_t *__restrict__ sel_kp,
-                                                int *__restrict__ sel_cnt, int *__restrict__ frame_status)
+template <int MAXN, bool INLDS>
+__device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G, const LevelGeom &L, const int K,
+                                            const int *__restrict__ ccnt_in, const uint32_t *__restrict__ ckp_in,
+                                            uint32_t *__restrict__ gkeys, unsigned short *__restrict__ gnode,
+                                            uint32_t *__restrict__ sel_kp, int *__restrict__ sel_cnt,
+                                            int *__restrict__ frame_status)
 {
-    __shared__ OctShared<MAXN> S;
+#define keys(k) (*(INLDS ? &S.lkeys[k] : &gkeys[k]))
+#define knode(k) (*(INLDS ? &S.lnode[k] : &gnode[k]))
     const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const LevelGeom L = G.lv[level];
-    uint32_t *keys = keys_ws + (size_t)b * G.cand_cap_total + L.cand_base;
-    unsigned short *knode = node_ws + (size_t)b * G.cand_cap_total + L.cand_base;
-    const int *ccnt_in = cell_cnt + (size_t)b * G.ncells_total + L.cell_base;
-    const uint32_t *ckp_in = cell_kp + ((size_t)b * G.ncells_total + L.cell_base) * G.slot_cap;
     const int N = L.quota;
     int tot;
-
-    // ---- gather the per-cell survivor lists into one array, reference order ----
-    int K = 0;
-    for (int c0 = 0; c0 < L.ncells; c0 += 256) {
-        int c = c0 + tid;
-        int n = c < L.ncells ? ccnt_in[c] : 0;
-        int base = block_excl_scan256(n, S.scan, &tot);
-        if (c < L.ncells) S.ccnt[c] = K + base;  // ncells <= MAXN*4 checked on the host
-        K += tot;
-    }
-    __syncthreads();
     for (int c = tid >> 4; c < L.ncells; c += 16) {  // 16 threads per cell
         int n = ccnt_in[c], base = S.ccnt[c];
-        for (int i = tid & 15; i < n; i += 16) keys[base + i] = ckp_in[(size_t)c * G.slot_cap + i];
+        for (int i = tid & 15; i < n; i += 16) keys(base + i) = ckp_in[(size_t)c * G.slot_cap + i];
     }
     __syncthreads();
 
@@ -453,10 +517,10 @@ __global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict
     }
     __syncthreads();
     for (int k = tid; k < K; k += 256) {
-        float x = (float)(keys[k] & 0xfffu);
+        float x = (float)(keys(k) & 0xfffu);
         int bin = (int)__fdiv_rn(x, L.hX);
         bin = min(bin, nIni - 1);
-        knode[k] = (unsigned short)bin;
+        knode(k) = (unsigned short)bin;
         atomicAdd(&S.ccnt[bin], 1);
     }
     __syncthreads();
@@ -480,7 +544,7 @@ __global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict
         }
         n = carry;
         __syncthreads();
-        for (int k = tid; k < K; k += 256) knode[k] = (unsigned short)S.nmap[knode[k]];
+        for (int k = tid; k < K; k += 256) knode(k) = (unsigned short)S.nmap[knode(k)];
         __syncthreads();
     }
     int cur = 1;
@@ -494,9 +558,9 @@ __global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict
         __syncthreads();
         // B: count children of expandable nodes (DivideNode :481-526)
         for (int k = tid; k < K; k += 256) {
-            int nd = knode[k];
+            int nd = knode(k);
             if (S.cnt[cur][nd] > 1) {
-                uint32_t kv = keys[k];
+                uint32_t kv = keys(k);
                 int x = kv & 0xfff, y = (kv >> 12) & 0xfff;
                 int mx = S.x0[cur][nd] + ((S.x1[cur][nd] - S.x0[cur][nd] + 1) >> 1);
                 int my = S.y0[cur][nd] + ((S.y1[cur][nd] - S.y0[cur][nd] + 1) >> 1);
@@ -615,19 +679,19 @@ __global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict
         __syncthreads();
         // F: relabel keys
         for (int k = tid; k < K; k += 256) {
-            int nd = knode[k];
+            int nd = knode(k);
             int mp = S.nmap[nd];
             if (mp & 0x40000000) {
-                uint32_t kv = keys[k];
+                uint32_t kv = keys(k);
                 int x = kv & 0xfff, y = (kv >> 12) & 0xfff;
                 int mx = S.x0[cur][nd] + ((S.x1[cur][nd] - S.x0[cur][nd] + 1) >> 1);
                 int my = S.y0[cur][nd] + ((S.y1[cur][nd] - S.y0[cur][nd] + 1) >> 1);
                 int q = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
                 int g = mp & 0x3fffffff;
                 for (int qq = 0; qq < q; ++qq) g += (S.ccnt[4 * nd + qq] > 0);
-                knode[k] = (unsigned short)(Gc - 1 - g);
+                knode(k) = (unsigned short)(Gc - 1 - g);
             } else {
-                knode[k] = (unsigned short)mp;
+                knode(k) = (unsigned short)mp;
             }
         }
         // G: bookkeeping (:669-673, :734)
@@ -648,17 +712,51 @@ __global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict
     for (int i = tid; i < n; i += 256) best[i] = 0;
     __syncthreads();
     for (int k = tid; k < K; k += 256) {
-        uint32_t kv = keys[k];
-        atomicMax(&best[knode[k]], ((kv >> 24) << 24) | (0xffffffu - (uint32_t)k));
+        uint32_t kv = keys(k);
+        atomicMax(&best[knode(k)], ((kv >> 24) << 24) | (0xffffffu - (uint32_t)k));
     }
     __syncthreads();
     uint32_t *out = sel_kp + (size_t)b * G.kp_cap_total + L.kp_base;
     const int nout = min(n, L.kp_cap);
-    for (int i = tid; i < nout; i += 256) out[i] = keys[0xffffffu - (best[i] & 0xffffffu)];
+    for (int i = tid; i < nout; i += 256) out[i] = keys(0xffffffu - (best[i] & 0xffffffu));
     if (tid == 0) {
         sel_cnt[b * ORBHIP_MAX_LEVELS + level] = nout;
         if (n > L.kp_cap) atomicExch(&frame_status[b], ORBHIP_E_CAPACITY);
     }
+#undef keys
+#undef knode
+}
+
+template <int MAXN>
+__global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict__ cell_cnt,
+                                                const uint32_t *__restrict__ cell_kp,
+                                                uint32_t *__restrict__ keys_ws,
+                                                unsigned short *__restrict__ node_ws,
+                                                uint32_t *__restrict__ sel_kp,
+                                                int *__restrict__ sel_cnt, int *__restrict__ frame_status)
+{
+    __shared__ OctShared<MAXN> S;
+    const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom L = G.lv[level];
+    uint32_t *gkeys = keys_ws + (size_t)b * G.cand_cap_total + L.cand_base;
+    unsigned short *gnode = node_ws + (size_t)b * G.cand_cap_total + L.cand_base;
+    const int *ccnt_in = cell_cnt + (size_t)b * G.ncells_total + L.cell_base;
+    const uint32_t *ckp_in = cell_kp + ((size_t)b * G.ncells_total + L.cell_base) * G.slot_cap;
+    int tot;
+    // ---- offsets of the per-cell survivor lists inside one array in reference order ----
+    int K = 0;
+    for (int c0 = 0; c0 < L.ncells; c0 += 256) {
+        int c = c0 + tid;
+        int n = c < L.ncells ? ccnt_in[c] : 0;
+        int base = block_excl_scan256(n, S.scan, &tot);
+        if (c < L.ncells) S.ccnt[c] = K + base;  // ncells <= MAXN*4 checked on the host
+        K += tot;
+    }
+    __syncthreads();
+    if (K <= kOctKeysLds)
+        octree_body<MAXN, true>(S, G, L, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
+    else
+        octree_body<MAXN, false>(S, G, L, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
 }
 
 // ---------------------------------------------------------------------------
@@ -669,14 +767,8 @@ __global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict
 // (<= 255*257) of rows 2r,2r+1 are stored interleaved in one dword so that the column pass is
 // three v_dot2_u32_u16 + one multiply per pixel; (sum + 2^15) >> 16, saturated; dword stores.
 // ---------------------------------------------------------------------------
-typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 constexpr int kBIn = kBlurTH + 6;   // staged input rows (64)
 constexpr int kBInW = 18;           // staged dwords per row: tile bytes x0-4 .. x0+67
-
-__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
-{
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b), c, false);
-}
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                               PyrGeom G, const TileDesc *__restrict__ tiles, BlurW W)
@@ -772,6 +864,14 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
     if (slot >= G.kp_cap_total) return;
+    // keypoint-independent operands first, so that their latency overlaps the slot lookup:
+    // this lane's 12 disc offsets (u | v << 8, zero padded) and its 4 rBRIEF test pairs
+    unsigned short duv[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) duv[i] = disc->uv[i * 64 + lane];
+    int pat[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pat[j] = pattern[j * 64 + lane];
     int level = 0;
     for (int l = 1; l < G.nlevels; ++l) if (slot >= G.lv[l].kp_base) level = l;
     const LevelGeom L = G.lv[level];
@@ -794,11 +894,17 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
     const uint8_t *c = pyr + fo + (size_t)ky * L.pitch + kx;
 
     int m10 = 0, m01 = 0;
-    for (int t = lane; t < 749; t += 64) {
-        int u = disc->u[t], v = disc->v[t];
-        int I = c[v * L.pitch + u];
-        m10 += u * I;
-        m01 += v * I;
+    int pix[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int u = (signed char)(duv[i] & 0xff), v = (signed char)(duv[i] >> 8);
+        pix[i] = c[v * L.pitch + u];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int u = (signed char)(duv[i] & 0xff), v = (signed char)(duv[i] >> 8);
+        m10 += u * pix[i];
+        m01 += v * pix[i];
     }
     m10 = wave_reduce_add(m10);
     m01 = wave_reduce_add(m01);
@@ -809,18 +915,21 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
     det_sincos(__fmul_rn(angle, factorPI), &a, &bsn);
     const uint8_t *cb = blur + fo + (size_t)ky * L.pitch + kx;
     unsigned long long bits[4];
+    int t0v[4], t1v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int pw = pattern[j * 64 + lane];
+        const int pw = pat[j];
         const float px0 = (float)(signed char)(pw & 0xff), py0 = (float)(signed char)((pw >> 8) & 0xff);
         const float px1 = (float)(signed char)((pw >> 16) & 0xff), py1 = (float)(signed char)((pw >> 24) & 0xff);
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, bsn), __fmul_rn(py0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, bsn)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, bsn), __fmul_rn(py1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, bsn)));
-        const int t0 = cb[r0 * L.pitch + c0], t1 = cb[r1 * L.pitch + c1];
-        bits[j] = __ballot(t0 < t1);
+        t0v[j] = cb[r0 * L.pitch + c0];
+        t1v[j] = cb[r1 * L.pitch + c1];
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bits[j] = __ballot(t0v[j] < t1v[j]);
     if (lane < 4) {
         unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
         reinterpret_cast<unsigned long long *>(out_desc + ((size_t)b * cap + oidx) * 32)[lane] = v;
@@ -937,21 +1046,28 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         L.kp_cap = std::max(L.quota + 3, 4 * nIni);
         L.kp_base = kp_base; kp_base += L.kp_cap;
         // resize tables for level l (from level l-1), OpenCV fixed-point arithmetic
-        L.xtab = (int)tabs.size();
+        auto align8 = [&]() { while (tabs.size() & 7) tabs.push_back(0); };
+        align8();
+        L.xtab = L.atab = L.ytab = (int)tabs.size();
         if (l > 0) {
             const int sw = G.lv[l - 1].w, shh = G.lv[l - 1].h;
             const double scale_x = 1. / ((double)L.w / sw), scale_y = 1. / ((double)L.h / shh);
+            std::vector<short> sxs, alph;
             for (int dx = 0; dx < L.w; ++dx) {
                 float fx = (float)((dx + 0.5) * scale_x - 0.5);
                 int sx = (int)floor(fx);
                 fx -= sx;
                 if (sx < 0) { fx = 0; sx = 0; }
                 if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
-                tabs.push_back((short)sx);
-                tabs.push_back((short)cv_round((1.f - fx) * 2048));
-                tabs.push_back((short)cv_round(fx * 2048));
+                sxs.push_back((short)sx);
+                alph.push_back((short)cv_round((1.f - fx) * 2048));
+                alph.push_back((short)cv_round(fx * 2048));
             }
-            if (tabs.size() & 1) tabs.push_back(0);
+            tabs.insert(tabs.end(), sxs.begin(), sxs.end());
+            align8();
+            L.atab = (int)tabs.size();
+            tabs.insert(tabs.end(), alph.begin(), alph.end());
+            align8();
             L.ytab = (int)tabs.size();
             for (int dy = 0; dy < L.h; ++dy) {
                 float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -1051,7 +1167,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
                            frame_stride, e->d_pyr, G);
         for (int l = 1; l < G.nlevels; ++l) {
             const LevelGeom &Ll = G.lv[l];
-            int nl = (Ll.pitch >> 2) * Ll.prows;
+            int nl = (Ll.pitch >> 2) * ((Ll.prows + kPyrRows - 1) / kPyrRows);
             hipLaunchKernelGGL(k_pyr_resize, dim3((nl + 255) / 256, batch), dim3(256), 0, s, e->d_pyr, G, l, e->d_tabs);
         }
     }
@@ -1135,15 +1251,13 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
     }
     e->stream = e->own_stream;
     // disc offsets in the reference's traversal order (order is irrelevant for integer sums)
-    DiscTab dt; memset(&dt, 0, sizeof(dt));
+    DiscTab dt; memset(&dt, 0, sizeof(dt));   // padding entries (u = v = 0) contribute 0 to both moments
     int nd = 0;
-    for (int u = -kHalfPatch; u <= kHalfPatch; ++u) { dt.u[nd] = (signed char)u; dt.v[nd] = 0; ++nd; }
+    auto put = [&](int u, int v) { dt.uv[nd++] = (unsigned short)((u & 0xff) | ((v & 0xff) << 8)); };
+    for (int u = -kHalfPatch; u <= kHalfPatch; ++u) put(u, 0);
     for (int vv = 1; vv <= kHalfPatch; ++vv) {
         int d = e->umax[vv];
-        for (int u = -d; u <= d; ++u) {
-            dt.u[nd] = (signed char)u; dt.v[nd] = (signed char)vv; ++nd;
-            dt.u[nd] = (signed char)u; dt.v[nd] = (signed char)-vv; ++nd;
-        }
+        for (int u = -d; u <= d; ++u) { put(u, vv); put(u, -vv); }
     }
     if (nd != 749) { set_error("disc table has %d entries", nd); orbhip_extractor_destroy(e); return ORBHIP_E_ARG; }
     if (hipMalloc(&e->d_disc, sizeof(DiscTab)) != hipSuccess || hipMalloc(&e->d_pattern, 256 * sizeof(int)) != hipSuccess) {

@@ -8,7 +8,7 @@ namespace orbhip {
 struct BlurW { int w[7]; };
 struct TileDesc { short level, tx, ty, pad; };
 constexpr int kBlurTW = 64, kBlurTH = 58;
-struct DiscTab { signed char u[768], v[768]; };  // 749 used
+struct DiscTab { unsigned short uv[768]; };  // 749 disc offsets (u | v << 8), zero padded to 12 x 64
 }  // namespace orbhip
 
 struct orbhip_extractor {
