@@ -317,12 +317,25 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     const int a = cd.x0 & 3;
     const int gxb = cd.x0 - a;                          // dword-aligned global column of LDS col 4
     const int ndw = (a + sw + 3) >> 2;                  // dwords per staged row
-    for (int i = lane; i < sh * kFStrideW; i += 64) {
-        int y = i / kFStrideW, wx = i - y * kFStrideW;
-        uint32_t v = 0;
-        if (wx >= 1 && wx <= ndw)
-            v = *reinterpret_cast<const uint32_t *>(roi + (size_t)(cd.y0 + y) * L.pitch + gxb + 4 * (wx - 1));
-        simg[i] = v;
+    {   // all global loads of a batch are issued before the first LDS store (one latency, not one per row)
+        constexpr int U = 8;
+        const int total = sh * kFStrideW;
+        for (int i0 = 0; i0 < total; i0 += 64 * U) {
+            uint32_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 64 + lane;
+                const int y = (i * 3121) >> 16, wx = i - y * kFStrideW;   // i / 21 for i < 6144
+                v[u] = 0;
+                if (i < total && wx >= 1 && wx <= ndw)
+                    v[u] = *reinterpret_cast<const uint32_t *>(roi + (size_t)(cd.y0 + y) * L.pitch + gxb + 4 * (wx - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 64 + lane;
+                if (i < total) simg[i] = v[u];
+            }
+        }
     }
     for (int i = lane; i < (dh + 2) * kFStrideW; i += 64) sscore[i] = 0;
     __syncthreads();
@@ -785,10 +798,21 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const int nin = rows + 6, npair = (nin + 1) >> 1;
     const int tid = threadIdx.x;
     const int gxmax = (L.w + 12) & ~3;
-    for (int i = tid; i < nin * kBInW; i += 256) {
-        const int r = i / kBInW, c = i - r * kBInW;
-        const int gy = min(y0 - 3 + r, L.h + kEdge - 1), gx = min(x0 - 4 + 4 * c, gxmax);
-        sin[i] = *reinterpret_cast<const uint32_t *>(roi + (ptrdiff_t)gy * L.pitch + gx);
+    {   // issue all staging loads of this thread before the first LDS store
+        constexpr int U = (kBIn * kBInW + 255) / 256;   // 5
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(u * 256 + tid, nin * kBInW - 1);
+            const int r = (i * 3641) >> 16, c = i - r * kBInW;   // i / 18 for i < 1152
+            const int gy = min(y0 - 3 + r, L.h + kEdge - 1), gx = min(x0 - 4 + 4 * c, gxmax);
+            v[u] = *reinterpret_cast<const uint32_t *>(roi + (ptrdiff_t)gy * L.pitch + gx);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = u * 256 + tid;
+            if (i < nin * kBInW) sin[i] = v[u];
+        }
     }
     const uint32_t wlo = (uint32_t)W.w[0] | ((uint32_t)W.w[1] << 8) | ((uint32_t)W.w[2] << 16) | ((uint32_t)W.w[3] << 24);
     const uint32_t whi = (uint32_t)W.w[4] | ((uint32_t)W.w[5] << 8) | ((uint32_t)W.w[6] << 16);
