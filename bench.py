@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--handles", type=int, default=1,
+                    help="extractor handles per GPU; the per-GPU batch is split evenly between them and their "
+                         "pipelines run concurrently on separate HIP streams")
     args = ap.parse_args()
 
     import torch
@@ -112,19 +115,34 @@ def main():
     frames = np.stack([uniq[1 + gidx % 16] for gidx in mine])
     d_img = torch.from_numpy(frames).to(dev)
 
-    ext = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
-    stream = torch.cuda.current_stream(dev)
-    ext.set_stream(stream.cuda_stream)          # launches go to torch's current stream
+    Hn = max(1, args.handles)
+    assert B % Hn == 0, "--frames-per-gpu must be a multiple of --handles"
+    Bh = B // Hn
+    exts, streams = [], []
+    for h in range(Hn):
+        e = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
+        st = torch.cuda.current_stream(dev) if Hn == 1 else torch.cuda.Stream(dev)
+        e.set_stream(st.cuda_stream)             # launches go to a torch-owned stream
+        exts.append(e)
+        streams.append(st)
+    ext = exts[0]
     cap = ext.capacity(H, W)
     d_kps = torch.zeros((B, cap, 7), dtype=torch.int32, device=dev)
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_n = torch.zeros(B, dtype=torch.int32, device=dev)
     d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
 
     def step():
-        ext.extract_batch_device(d_img.data_ptr(), B, H, W, d_kps.data_ptr(), d_desc.data_ptr(), cap,
-                                 d_n.data_ptr(), d_st.data_ptr())
+        for h, e in enumerate(exts):
+            sl = slice(h * Bh, (h + 1) * Bh)
+            e.extract_batch_device(d_img[sl].data_ptr(), Bh, H, W, d_kps[sl].data_ptr(), d_desc[sl].data_ptr(), cap,
+                                   d_n[sl].data_ptr(), d_st[sl].data_ptr())
         if world > 1:
+            for st in streams[1:] if Hn > 1 else []:
+                torch.cuda.current_stream(dev).wait_stream(st)
+            if Hn > 1:
+                torch.cuda.current_stream(dev).wait_stream(streams[0])
             return gather_to_rank0(d_kps, d_desc, d_n)
         return None
 
@@ -136,14 +154,17 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ext.set_profiling(True)                     # HIP events around every stage, on the launch stream
+    for e in exts:
+        e.set_profiling(True)                   # HIP events around every stage, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    stage = ext.stage_times_us()
-    ext.set_profiling(False)
+    stages = [e.stage_times_us() for e in exts]
+    stage = {k: sum(st[k] for st in stages) / len(stages) for k in stages[0]}
+    for e in exts:
+        e.set_profiling(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -157,7 +178,7 @@ def main():
         kern = max(("pyramid", "fast", "octree", "blur", "describe"), key=lambda k: stage[k])
         if ALGO_BYTES[kern] == 0:   # the octree moves no pixel data: price the next stage instead
             kern = max(("pyramid", "fast", "blur", "describe"), key=lambda k: stage[k])
-        algo = ALGO_BYTES[kern] * B
+        algo = ALGO_BYTES[kern] * Bh                # frames per launch of one handle
         achieved = algo / (stage[kern] * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -175,7 +196,8 @@ def main():
             "config": {"workload": "configs[1]: synthetic 1241x376 u8 frames resident in HBM, nFeatures=1000, "
                                    "8-level pyramid, extract-only" +
                                    ("; configs[3]: one frame per GPU round-robin + RCCL gather to rank 0" if world > 1 else ""),
-                       "frames_per_gpu_per_step": B, "global_batch": B * world, "nfeatures": NFEAT,
+                       "frames_per_gpu_per_step": B, "handles_per_gpu": Hn, "frames_per_launch": Bh,
+                       "global_batch": B * world, "nfeatures": NFEAT,
                        "levels": NLEVELS, "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
                        "parallelism": "frame-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_pyr_level0+k_pyr_resize(x7)", "fast": "k_fast_cells",
@@ -185,7 +207,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo,
                          "avg_launch_us": round(stage[kern], 2),
                          "stage_us": {k: round(v, 2) for k, v in stage.items()},
-                         "whole_path_GBps_model": round(FRAME_BYTES_MODEL * B / (stage["total"] * 1e-6) / 1e9, 2)},
+                         "whole_path_GBps_model": round(FRAME_BYTES_MODEL * fps / world / 1e9, 2)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames[:16])

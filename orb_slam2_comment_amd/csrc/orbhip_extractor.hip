@@ -30,6 +30,19 @@ void set_error(const char *fmt, ...)
 // ---------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------
+// XCD-aware work mapping (speed only, never correctness): workgroups are dealt round-robin over the
+// 8 XCDs in linear order, each XCD has a private 4 MB L2.  Re-index so that XCD k owns a contiguous
+// run of (frame, unit) pairs: with a batch that is a multiple of 8 every kernel of the pipeline
+// then touches frame f from the same XCD, and neighbouring cells/tiles share their cache lines.
+__device__ __forceinline__ void xcd_remap(int &unit, int &frame)
+{
+    const unsigned T = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned q = T >> 3, r = T & 7, x = lin & 7;
+    const unsigned lin2 = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3);
+    frame = (int)(lin2 / gridDim.x);
+    unit = (int)(lin2 - (unsigned)frame * gridDim.x);
+}
+
 __device__ __forceinline__ int wave_reduce_add(int v)
 {
 #pragma unroll
@@ -137,11 +150,13 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ 
 {
     const LevelGeom L = G.lv[0];
     const int words = L.pitch >> 2;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int bx, fr;
+    xcd_remap(bx, fr);
+    const int idx = bx * 256 + threadIdx.x;
     if (idx >= words * L.prows) return;
     const int py = idx / words, pw = idx - py * words;
-    const uint8_t *src = images + (size_t)blockIdx.y * frame_stride;
-    uint8_t *dst = pyr + (size_t)blockIdx.y * G.frame_bytes + L.plane_off;
+    const uint8_t *src = images + (size_t)fr * frame_stride;
+    uint8_t *dst = pyr + (size_t)fr * G.frame_bytes + L.plane_off;
     const int sy = reflect101(py - kEdge, L.h);
     const uint8_t *srow = src + (size_t)sy * stride;
     uint32_t out = 0;
@@ -178,10 +193,12 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
     const LevelGeom P = G.lv[level - 1];
     const int words = L.pitch >> 2;
     const int nquads = (L.prows + kPyrRows - 1) / kPyrRows;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int bx, fr;
+    xcd_remap(bx, fr);
+    const int idx = bx * 256 + threadIdx.x;
     if (idx >= words * nquads) return;
     const int rq = idx / words, pw = idx - rq * words;
-    uint8_t *frame = pyr + (size_t)blockIdx.y * G.frame_bytes;
+    uint8_t *frame = pyr + (size_t)fr * G.frame_bytes;
     const uint8_t *sroi = frame + P.plane_off + (size_t)kEdge * P.pitch + kPadL;
     uint8_t *dst = frame + L.plane_off;
     const int x0 = pw * 4 - kPadL;
@@ -279,8 +296,6 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
 //     by rank counting over the (few) survivors.
 // ---------------------------------------------------------------------------
 constexpr int kSubMax = 72;              // max (wCell+6), (hCell+6)
-constexpr int kFStride = 84;             // LDS row stride in bytes (21 dwords): 4 margin + <=75 + spare
-constexpr int kFStrideW = kFStride / 4;
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
@@ -288,26 +303,33 @@ __device__ __forceinline__ int lane_prefix(unsigned long long m)
 {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i16x2_t as_i16x2(uint32_t v) { return __builtin_bit_cast(i16x2_t, v); }
+// bytes (b0,b1) / (b2,b3) of a dword zero-extended to two int16 lanes
+__device__ __forceinline__ i16x2_t bytes01(uint32_t v) { return as_i16x2(__builtin_amdgcn_perm(0u, v, 0x0c010c00u)); }
+__device__ __forceinline__ i16x2_t bytes23(uint32_t v) { return as_i16x2(__builtin_amdgcn_perm(0u, v, 0x0c030c02u)); }
 
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, PyrGeom G,
                                                    const CellDesc *__restrict__ cells,
                                                    int *__restrict__ cell_cnt,
-                                                   uint32_t *__restrict__ cell_kp, int lds_img_words,
-                                                   int lds_score_words, int lds_list_words)
+                                                   uint32_t *__restrict__ cell_kp, FastLds F)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *simg = lds;                                   // staged sub-image
-    uint32_t *sscore = lds + lds_img_words;                 // score map, 1-px zero halo rows
-    unsigned short *slist = reinterpret_cast<unsigned short *>(sscore + lds_score_words);  // (y<<7)|col
-    uint32_t *sfinal = sscore + lds_score_words + lds_list_words;                          // NMS survivors
+    uint32_t *sscore = lds + F.img_words;                   // score map, 1-px zero halo rows
+    unsigned short *slist = reinterpret_cast<unsigned short *>(sscore + F.score_words);  // (y<<7)|col
+    uint32_t *sfinal = sscore + F.score_words + F.list_words;                            // NMS survivors
 
-    const CellDesc cd = cells[blockIdx.x];
+    int cell, fr;
+    xcd_remap(cell, fr);
+    const CellDesc cd = cells[cell];
     const LevelGeom L = G.lv[cd.level];
-    const uint8_t *roi = pyr + (size_t)blockIdx.y * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
+    const uint8_t *roi = pyr + (size_t)fr * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
     const int sw = cd.x1 - cd.x0, sh = cd.y1 - cd.y0;  // sub-image size
     const int dw = sw - 6, dh = sh - 6;                // detection rectangle
     const int lane = threadIdx.x;
-    const size_t out_cell = (size_t)blockIdx.y * G.ncells_total + blockIdx.x;
+    const size_t out_cell = (size_t)fr * G.ncells_total + cell;
+    const int SW = F.strideW, SB = F.strideW * 4;
 
     if (dw <= 0 || dh <= 0) {  // cv::FAST on an image narrower than 7 px finds nothing
         if (lane == 0) cell_cnt[out_cell] = 0;
@@ -318,14 +340,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     const int gxb = cd.x0 - a;                          // dword-aligned global column of LDS col 4
     const int ndw = (a + sw + 3) >> 2;                  // dwords per staged row
     {   // all global loads of a batch are issued before the first LDS store (one latency, not one per row)
-        constexpr int U = 8;
-        const int total = sh * kFStrideW;
+        constexpr int U = 10;
+        const int total = sh * SW;
         for (int i0 = 0; i0 < total; i0 += 64 * U) {
             uint32_t v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = i0 + u * 64 + lane;
-                const int y = (i * 3121) >> 16, wx = i - y * kFStrideW;   // i / 21 for i < 6144
+                const int y = (i * F.div_magic) >> 20, wx = i - y * SW;
                 v[u] = 0;
                 if (i < total && wx >= 1 && wx <= ndw)
                     v[u] = *reinterpret_cast<const uint32_t *>(roi + (size_t)(cd.y0 + y) * L.pitch + gxb + 4 * (wx - 1));
@@ -337,7 +359,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             }
         }
     }
-    for (int i = lane; i < (dh + 2) * kFStrideW; i += 64) sscore[i] = 0;
+    for (int i = lane; i < (dh + 2) * SW; i += 64) sscore[i] = 0;
     __syncthreads();
 
     // column groups: group g covers LDS cols 4g..4g+3; valid centre cols [c_lo, c_hi)
@@ -347,36 +369,47 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     const int nwork = ngrp * dh;                        // (row, group) work items, row-major
     const int magic = ((1 << 20) + ngrp - 1) / ngrp;    // exact floor(i/ngrp) for i < 4096
     const int tmin = G.min_th;
+    const i16x2_t T2 = {(short)tmin, (short)tmin};
 
-    // ---- 2. dense pre-test, survivors -> slist ----
+    // ---- 2. dense pre-test (packed int16, two pixels per operation), survivors -> slist ----
     int nsurv = 0;
     for (int it0 = 0; it0 < nwork; it0 += 64) {
         const int it = it0 + lane;
         const int y = (it * magic) >> 20;               // detection row; sub-image row y+3
         const int g = g_lo + it - y * ngrp;
-        uint32_t c0 = 0, c1 = 0, c2 = 0, up = 0, dn = 0;
+        uint32_t keepm = 0;
         if (it < nwork) {
-            const uint32_t *p = &simg[(y + 3) * kFStrideW + g - 1];
-            c0 = p[0]; c1 = p[1]; c2 = p[2];
-            up = simg[y * kFStrideW + g];
-            dn = simg[(y + 6) * kFStrideW + g];
+            const uint32_t *p = &simg[(y + 3) * SW + g - 1];
+            const uint32_t c0 = p[0], c1 = p[1], c2 = p[2];
+            const uint32_t up = simg[y * SW + g], dn = simg[(y + 6) * SW + g];
+            const uint32_t e4 = __builtin_amdgcn_alignbyte(c2, c1, 3);    // ring pixel 4  (x+3): bytes 7..10
+            const uint32_t e12 = __builtin_amdgcn_alignbyte(c1, c0, 1);   // ring pixel 12 (x-3): bytes 1..4
+            uint32_t m[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const i16x2_t v = h ? bytes23(c1) : bytes01(c1);
+                const i16x2_t d0 = (h ? bytes23(dn) : bytes01(dn)) - v, d8 = (h ? bytes23(up) : bytes01(up)) - v;
+                const i16x2_t d4 = (h ? bytes23(e4) : bytes01(e4)) - v, d12 = (h ? bytes23(e12) : bytes01(e12)) - v;
+                // bright arc needs (p0|p8) and (p4|p12) brighter than v+t; dark arc the mirror image
+                const i16x2_t br = __builtin_elementwise_min(__builtin_elementwise_max(d0, d8), __builtin_elementwise_max(d4, d12));
+                const i16x2_t dk = __builtin_elementwise_max(__builtin_elementwise_min(d0, d8), __builtin_elementwise_min(d4, d12));
+                const i16x2_t s1 = T2 - br, s2 = dk + T2;   // negative <=> br > t, dk < -t
+                m[h] = (__builtin_bit_cast(uint32_t, s1) | __builtin_bit_cast(uint32_t, s2)) & 0x80008000u;
+            }
+            const int col0 = 4 * g;
+            keepm = ((m[0] >> 15) & 1u) | ((m[0] >> 30) & 2u) | ((m[1] >> 13) & 4u) | ((m[1] >> 28) & 8u);
+            // mask centres outside the detection rectangle
+            uint32_t vm = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vm |= (uint32_t)(col0 + j >= c_lo && col0 + j < c_hi) << j;
+            keepm &= vm;
         }
-        const unsigned long long win = ((unsigned long long)c1 << 32) | c0;   // bytes 0..7 of the row window
-        const unsigned long long win2 = ((unsigned long long)c2 << 32) | c1;  // bytes 4..11
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int col = 4 * g + j;
-            const int v = (int)((c1 >> (8 * j)) & 0xff);
-            const int p0 = (int)((dn >> (8 * j)) & 0xff), p8 = (int)((up >> (8 * j)) & 0xff);
-            const int p4 = (int)((win2 >> (8 * (3 + j))) & 0xff);    // byte 7+j
-            const int p12 = (int)((win >> (8 * (1 + j))) & 0xff);    // byte 1+j
-            const int hi = v + tmin, lo = v - tmin;
-            const bool pre = it < nwork && col >= c_lo && col < c_hi &&
-                             ((((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi))) |
-                              (((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo))));
-            const unsigned long long m = __ballot(pre);
-            if (pre) slist[nsurv + lane_prefix(m)] = (unsigned short)((y << 7) | col);
-            nsurv += __popcll(m);
+            const bool pre = (keepm >> j) & 1u;
+            const unsigned long long bm = __ballot(pre);
+            if (pre) slist[nsurv + lane_prefix(bm)] = (unsigned short)((y << 7) | (4 * g + j));
+            nsurv += __popcll(bm);
         }
     }
     __syncthreads();
@@ -392,17 +425,17 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         if (i < nsurv) {
             e = slist[i];
             const int y = e >> 7, col = e & 127;
-            const uint8_t *c = img8 + (y + 3) * kFStride + col;
+            const uint8_t *c = img8 + (y + 3) * SB + col;
             const int v = c[0];
             int d[16];
-            d[0] = v - c[3 * kFStride];       d[1] = v - c[3 * kFStride + 1];
-            d[2] = v - c[2 * kFStride + 2];   d[3] = v - c[kFStride + 3];
-            d[4] = v - c[3];                  d[5] = v - c[-kFStride + 3];
-            d[6] = v - c[-2 * kFStride + 2];  d[7] = v - c[-3 * kFStride + 1];
-            d[8] = v - c[-3 * kFStride];      d[9] = v - c[-3 * kFStride - 1];
-            d[10] = v - c[-2 * kFStride - 2]; d[11] = v - c[-kFStride - 3];
-            d[12] = v - c[-3];                d[13] = v - c[kFStride - 3];
-            d[14] = v - c[2 * kFStride - 2];  d[15] = v - c[3 * kFStride - 1];
+            d[0] = v - c[3 * SB];       d[1] = v - c[3 * SB + 1];
+            d[2] = v - c[2 * SB + 2];   d[3] = v - c[SB + 3];
+            d[4] = v - c[3];            d[5] = v - c[-SB + 3];
+            d[6] = v - c[-2 * SB + 2];  d[7] = v - c[-3 * SB + 1];
+            d[8] = v - c[-3 * SB];      d[9] = v - c[-3 * SB - 1];
+            d[10] = v - c[-2 * SB - 2]; d[11] = v - c[-SB - 3];
+            d[12] = v - c[-3];          d[13] = v - c[SB - 3];
+            d[14] = v - c[2 * SB - 2];  d[15] = v - c[3 * SB - 1];
             int m3[16], M3[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -421,7 +454,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             brn = min3i(brn, min3i(mx9[9], mx9[10], mx9[11]), min3i(mx9[12], mx9[13], min(mx9[14], mx9[15])));
             const int sc = max(dark, -brn) - 1;       // cornerScore; corner at minTh <=> S >= minTh
             isc = sc >= tmin;
-            if (isc) score8[(y + 1) * kFStride + col] = (uint8_t)min(sc, 255);
+            if (isc) score8[(y + 1) * SB + col] = (uint8_t)min(sc, 255);
         }
         const unsigned long long m = __ballot(isc);
         if (isc) slist[ncorn + lane_prefix(m)] = e;     // write index <= read index: in place is safe
@@ -438,10 +471,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         if (i < ncorn) {
             const unsigned short e = slist[i];
             const int y = e >> 7, col = e & 127;
-            const uint8_t *s = score8 + (y + 1) * kFStride + col;
+            const uint8_t *s = score8 + (y + 1) * SB + col;
             const int v = s[0];
-            keep = v > s[-1] && v > s[1] && v > s[-kFStride - 1] && v > s[-kFStride] && v > s[-kFStride + 1] &&
-                   v > s[kFStride - 1] && v > s[kFStride] && v > s[kFStride + 1];
+            keep = v > s[-1] && v > s[1] && v > s[-SB - 1] && v > s[-SB] && v > s[-SB + 1] &&
+                   v > s[SB - 1] && v > s[SB] && v > s[SB + 1];
             key = ((uint32_t)e << 8) | (uint32_t)v;
         }
         const unsigned long long m = __ballot(keep);
@@ -483,6 +516,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 // key count, newer node first, until the list reaches N), rebuilds the node table in
 // list order (new children reversed in front, survivors behind) and relabels keys.
 // ---------------------------------------------------------------------------
+constexpr int kOctU = 4;            // independent keys per thread in the key loops
 constexpr int kOctKeysLds = 6144;   // keys held in LDS (36 KB); larger levels use the HBM workspace
 
 template <int MAXN>
@@ -501,7 +535,8 @@ struct OctShared {
 };
 
 template <int MAXN, bool INLDS>
-__device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G, const LevelGeom &L, const int K,
+__device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G, const LevelGeom &L,
+                                            const int level, const int b, const int K,
                                             const int *__restrict__ ccnt_in, const uint32_t *__restrict__ ckp_in,
                                             uint32_t *__restrict__ gkeys, unsigned short *__restrict__ gnode,
                                             uint32_t *__restrict__ sel_kp, int *__restrict__ sel_cnt,
@@ -509,12 +544,31 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
 {
 #define keys(k) (*(INLDS ? &S.lkeys[k] : &gkeys[k]))
 #define knode(k) (*(INLDS ? &S.lnode[k] : &gnode[k]))
-    const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int N = L.quota;
     int tot;
-    for (int c = tid >> 4; c < L.ncells; c += 16) {  // 16 threads per cell
-        int n = ccnt_in[c], base = S.ccnt[c];
-        for (int i = tid & 15; i < n; i += 16) keys(base + i) = ckp_in[(size_t)c * G.slot_cap + i];
+    // gather the per-cell survivor lists into one array in reference order: flat loop over the K keys,
+    // owning cell by binary search over the exclusive offsets in S.ccnt (loads stay independent)
+    for (int k0 = 0; k0 < K; k0 += 256 * 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 256 + tid;
+            v[u] = 0;
+            if (k < K) {
+                int lo = 0, hi = L.ncells - 1;      // last cell c with S.ccnt[c] <= k
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (S.ccnt[mid] <= k) lo = mid; else hi = mid - 1;
+                }
+                v[u] = ckp_in[(size_t)lo * G.slot_cap + (k - S.ccnt[lo])];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 256 + tid;
+            if (k < K) keys(k) = v[u];
+        }
     }
     __syncthreads();
 
@@ -529,12 +583,19 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         S.ccnt[i] = 0;
     }
     __syncthreads();
-    for (int k = tid; k < K; k += 256) {
-        float x = (float)(keys(k) & 0xfffu);
-        int bin = (int)__fdiv_rn(x, L.hX);
-        bin = min(bin, nIni - 1);
-        knode(k) = (unsigned short)bin;
-        atomicAdd(&S.ccnt[bin], 1);
+    for (int k0 = 0; k0 < K; k0 += 256 * kOctU) {
+        uint32_t kv[kOctU];
+#pragma unroll
+        for (int u = 0; u < kOctU; ++u) { const int k = k0 + u * 256 + tid; kv[u] = k < K ? keys(k) : 0u; }
+#pragma unroll
+        for (int u = 0; u < kOctU; ++u) {
+            const int k = k0 + u * 256 + tid;
+            if (k < K) {
+                const int bin = min((int)__fdiv_rn((float)(kv[u] & 0xfffu), L.hX), nIni - 1);
+                knode(k) = (unsigned short)bin;
+                atomicAdd(&S.ccnt[bin], 1);
+            }
+        }
     }
     __syncthreads();
     int n = 0;  // list size
@@ -557,7 +618,15 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         }
         n = carry;
         __syncthreads();
-        for (int k = tid; k < K; k += 256) knode(k) = (unsigned short)S.nmap[knode(k)];
+        for (int k0 = 0; k0 < K; k0 += 256 * kOctU) {
+            int nd[kOctU];
+#pragma unroll
+            for (int u = 0; u < kOctU; ++u) { const int k = k0 + u * 256 + tid; nd[u] = k < K ? (int)knode(k) : 0; }
+#pragma unroll
+            for (int u = 0; u < kOctU; ++u) nd[u] = S.nmap[nd[u]];
+#pragma unroll
+            for (int u = 0; u < kOctU; ++u) { const int k = k0 + u * 256 + tid; if (k < K) knode(k) = (unsigned short)nd[u]; }
+        }
         __syncthreads();
     }
     int cur = 1;
@@ -570,15 +639,32 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         for (int i = tid; i < n * 4; i += 256) S.ccnt[i] = 0;
         __syncthreads();
         // B: count children of expandable nodes (DivideNode :481-526)
-        for (int k = tid; k < K; k += 256) {
-            int nd = knode(k);
-            if (S.cnt[cur][nd] > 1) {
-                uint32_t kv = keys(k);
-                int x = kv & 0xfff, y = (kv >> 12) & 0xfff;
-                int mx = S.x0[cur][nd] + ((S.x1[cur][nd] - S.x0[cur][nd] + 1) >> 1);
-                int my = S.y0[cur][nd] + ((S.y1[cur][nd] - S.y0[cur][nd] + 1) >> 1);
-                int q = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
-                atomicAdd(&S.ccnt[4 * nd + q], 1);
+        for (int k0 = 0; k0 < K; k0 += 256 * kOctU) {
+            // kOctU independent keys per thread: the LDS round trips of the chains overlap
+            int nd[kOctU], cn[kOctU];
+            uint32_t kv[kOctU];
+#pragma unroll
+            for (int u = 0; u < kOctU; ++u) {
+                const int k = k0 + u * 256 + tid;
+                nd[u] = k < K ? (int)knode(k) : 0;
+                kv[u] = k < K ? keys(k) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kOctU; ++u) cn[u] = S.cnt[cur][nd[u]];
+            int bx0[kOctU], bx1[kOctU], by0[kOctU], by1[kOctU];
+#pragma unroll
+            for (int u = 0; u < kOctU; ++u) {
+                bx0[u] = S.x0[cur][nd[u]]; bx1[u] = S.x1[cur][nd[u]];
+                by0[u] = S.y0[cur][nd[u]]; by1[u] = S.y1[cur][nd[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < kOctU; ++u) {
+                const int k = k0 + u * 256 + tid;
+                if (k < K && cn[u] > 1) {
+                    const int x = kv[u] & 0xfff, y = (kv[u] >> 12) & 0xfff;
+                    const int mx = bx0[u] + ((bx1[u] - bx0[u] + 1) >> 1), my = by0[u] + ((by1[u] - by0[u] + 1) >> 1);
+                    atomicAdd(&S.ccnt[4 * nd[u] + (x < mx ? 0 : 1) + (y < my ? 0 : 2)], 1);
+                }
             }
         }
         __syncthreads();
@@ -605,6 +691,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
                 int r = 0;
                 if (e) {
                     int ci = S.cnt[cur][i];
+#pragma unroll 8
                     for (int j = 0; j < n; ++j) {
                         int cj = S.cnt[cur][j];
                         r += (cj > 1) && (cj > ci || (cj == ci && j < i));
@@ -691,20 +778,38 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         }
         __syncthreads();
         // F: relabel keys
-        for (int k = tid; k < K; k += 256) {
-            int nd = knode(k);
-            int mp = S.nmap[nd];
-            if (mp & 0x40000000) {
-                uint32_t kv = keys(k);
-                int x = kv & 0xfff, y = (kv >> 12) & 0xfff;
-                int mx = S.x0[cur][nd] + ((S.x1[cur][nd] - S.x0[cur][nd] + 1) >> 1);
-                int my = S.y0[cur][nd] + ((S.y1[cur][nd] - S.y0[cur][nd] + 1) >> 1);
-                int q = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
-                int g = mp & 0x3fffffff;
-                for (int qq = 0; qq < q; ++qq) g += (S.ccnt[4 * nd + qq] > 0);
-                knode(k) = (unsigned short)(Gc - 1 - g);
-            } else {
-                knode(k) = (unsigned short)mp;
+        for (int k0 = 0; k0 < K; k0 += 256 * kOctU) {
+            int nd[kOctU], mp[kOctU];
+            uint32_t kv[kOctU];
+#pragma unroll
+            for (int u = 0; u < kOctU; ++u) {
+                const int k = k0 + u * 256 + tid;
+                nd[u] = k < K ? (int)knode(k) : 0;
+                kv[u] = k < K ? keys(k) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kOctU; ++u) mp[u] = S.nmap[nd[u]];
+            int bx0[kOctU], bx1[kOctU], by0[kOctU], by1[kOctU], c0[kOctU], c1[kOctU], c2[kOctU];
+#pragma unroll
+            for (int u = 0; u < kOctU; ++u) {
+                bx0[u] = S.x0[cur][nd[u]]; bx1[u] = S.x1[cur][nd[u]];
+                by0[u] = S.y0[cur][nd[u]]; by1[u] = S.y1[cur][nd[u]];
+                c0[u] = S.ccnt[4 * nd[u]]; c1[u] = S.ccnt[4 * nd[u] + 1]; c2[u] = S.ccnt[4 * nd[u] + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < kOctU; ++u) {
+                const int k = k0 + u * 256 + tid;
+                if (k >= K) continue;
+                if (mp[u] & 0x40000000) {
+                    const int x = kv[u] & 0xfff, y = (kv[u] >> 12) & 0xfff;
+                    const int mx = bx0[u] + ((bx1[u] - bx0[u] + 1) >> 1), my = by0[u] + ((by1[u] - by0[u] + 1) >> 1);
+                    const int q = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
+                    int g = mp[u] & 0x3fffffff;
+                    g += (q > 0 && c0[u] > 0) + (q > 1 && c1[u] > 0) + (q > 2 && c2[u] > 0);
+                    knode(k) = (unsigned short)(Gc - 1 - g);
+                } else {
+                    knode(k) = (unsigned short)mp[u];
+                }
             }
         }
         // G: bookkeeping (:669-673, :734)
@@ -724,9 +829,20 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
     unsigned int *best = reinterpret_cast<unsigned int *>(S.ccnt);
     for (int i = tid; i < n; i += 256) best[i] = 0;
     __syncthreads();
-    for (int k = tid; k < K; k += 256) {
-        uint32_t kv = keys(k);
-        atomicMax(&best[knode(k)], ((kv >> 24) << 24) | (0xffffffu - (uint32_t)k));
+    for (int k0 = 0; k0 < K; k0 += 256 * kOctU) {
+        int nd[kOctU];
+        uint32_t kv[kOctU];
+#pragma unroll
+        for (int u = 0; u < kOctU; ++u) {
+            const int k = k0 + u * 256 + tid;
+            nd[u] = k < K ? (int)knode(k) : 0;
+            kv[u] = k < K ? keys(k) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kOctU; ++u) {
+            const int k = k0 + u * 256 + tid;
+            if (k < K) atomicMax(&best[nd[u]], ((kv[u] >> 24) << 24) | (0xffffffu - (uint32_t)k));
+        }
     }
     __syncthreads();
     uint32_t *out = sel_kp + (size_t)b * G.kp_cap_total + L.kp_base;
@@ -749,7 +865,9 @@ __global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict
                                                 int *__restrict__ sel_cnt, int *__restrict__ frame_status)
 {
     __shared__ OctShared<MAXN> S;
-    const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    int level, b;
+    xcd_remap(level, b);
+    const int tid = threadIdx.x;
     const LevelGeom L = G.lv[level];
     uint32_t *gkeys = keys_ws + (size_t)b * G.cand_cap_total + L.cand_base;
     unsigned short *gnode = node_ws + (size_t)b * G.cand_cap_total + L.cand_base;
@@ -767,9 +885,9 @@ __global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict
     }
     __syncthreads();
     if (K <= kOctKeysLds)
-        octree_body<MAXN, true>(S, G, L, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
+        octree_body<MAXN, true>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
     else
-        octree_body<MAXN, false>(S, G, L, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
+        octree_body<MAXN, false>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
 }
 
 // ---------------------------------------------------------------------------
@@ -788,9 +906,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 {
     __shared__ uint32_t sin[kBIn * kBInW];
     __shared__ uint4 srow[(kBIn / 2) * (kBlurTW / 4)];   // [pair-row][group]: 4 px x (row 2r | row 2r+1 << 16)
-    const TileDesc t = tiles[blockIdx.x];
+    int tile, fr;
+    xcd_remap(tile, fr);
+    const TileDesc t = tiles[tile];
     const LevelGeom L = G.lv[t.level];
-    const size_t fo = (size_t)blockIdx.y * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
+    const size_t fo = (size_t)fr * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
     const uint8_t *roi = pyr + fo;
     uint8_t *out = blur + fo;
     const int x0 = t.tx * kBlurTW, y0 = t.ty * kBlurTH;
@@ -885,8 +1005,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
                                                          int *__restrict__ out_n, int *__restrict__ status)
 {
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int b = blockIdx.y;
+    int bx, b;
+    xcd_remap(bx, b);
+    const int slot = bx * 4 + (threadIdx.x >> 6);
     if (slot >= G.kp_cap_total) return;
     // keypoint-independent operands first, so that their latency overlaps the slot lookup:
     // this lane's 12 disc offsets (u | v << 8, zero padded) and its 4 rBRIEF test pairs
@@ -1112,16 +1233,21 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
             }
     }
     {   // dynamic LDS carve-up of k_fast_cells from the largest cell of this geometry
-        int msh = 7, mdh = 1, mdw = 1;
+        int msh = 7, mdh = 1, mdw = 1, mndw = 2;
         for (const CellDesc &c : e->cells) {
             msh = std::max(msh, c.y1 - c.y0);
             mdh = std::max(mdh, c.y1 - c.y0 - 6);
             mdw = std::max(mdw, c.x1 - c.x0 - 6);
+            mndw = std::max(mndw, ((c.x0 & 3) + (c.x1 - c.x0) + 3) >> 2);
         }
-        e->fast_lds_words[0] = msh * kFStrideW;
-        e->fast_lds_words[1] = (mdh + 2) * kFStrideW;
-        e->fast_lds_words[2] = (mdw * mdh + 1) / 2 + 1;   // uint16 list: every pixel may pass the pre-test
-        e->fast_lds_words[3] = slot_cap + 64;
+        FastLds &F = e->fast_lds;
+        F.strideW = (mndw + 2) | 1;                       // margin + spare, odd: rows rotate over the LDS banks
+        F.div_magic = ((1 << 20) + F.strideW - 1) / F.strideW;
+        F.img_words = msh * F.strideW;
+        F.score_words = (mdh + 2) * F.strideW;
+        F.list_words = (mdw * mdh + 1) / 2 + 1;           // uint16 list: every pixel may pass the pre-test
+        e->fast_lds_bytes = (F.img_words + F.score_words + F.list_words + slot_cap + 64) * 4;
+        if (F.strideW * 4 > 127 || msh * F.strideW >= 8192) { set_error("cell geometry exceeds the FAST kernel limits"); return ORBHIP_E_SIZE; }
     }
     G.frame_bytes = off;
     G.ncells_total = (int)e->cells.size();
@@ -1180,8 +1306,9 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     const PyrGeom &G = e->G;
     hipStream_t s = e->stream;
     const bool prof = e->profiling;
-    hipEvent_t *ev = prof ? &e->ev[(size_t)(e->prof_calls % orbhip_extractor::kProfRing) * 6] : nullptr;
+    hipEvent_t *ev = prof ? &e->ev[(size_t)(e->prof_calls % orbhip_extractor::kProfRing) * orbhip_extractor::kProfEv] : nullptr;
     int *status = d_status ? d_status : e->d_status;
+    hipStream_t s2 = e->aux_stream;
     hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
     if (prof) hipEventRecord(ev[0], s);
     {
@@ -1196,11 +1323,18 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         }
     }
     if (prof) hipEventRecord(ev[1], s);
+    // fork: the blur only needs the pyramid; it is HBM-bound while FAST is VALU-bound and the octree is
+    // latency-bound, so it runs beside them on the auxiliary stream and joins before the descriptors
+    hipEventRecord(e->ev_pyr, s);
+    hipStreamWaitEvent(s2, e->ev_pyr, 0);
+    if (prof) hipEventRecord(ev[6], s2);
+    hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s2, e->d_pyr, e->d_blur, G,
+                       e->d_tiles, e->blurw);
+    if (prof) hipEventRecord(ev[7], s2);
+    hipEventRecord(e->ev_blur, s2);
     if (G.ncells_total > 0)
-        hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, batch), dim3(64),
-                           (size_t)(e->fast_lds_words[0] + e->fast_lds_words[1] + e->fast_lds_words[2] + e->fast_lds_words[3]) * 4,
-                           s, e->d_pyr, G, e->d_cells, e->d_cell_cnt, e->d_cell_kp, e->fast_lds_words[0],
-                           e->fast_lds_words[1], e->fast_lds_words[2]);
+        hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, batch), dim3(64), (size_t)e->fast_lds_bytes, s, e->d_pyr, G,
+                           e->d_cells, e->d_cell_cnt, e->d_cell_kp, e->fast_lds);
     if (prof) hipEventRecord(ev[2], s);
     if (e->octree_maxn == 512)
         hipLaunchKernelGGL(k_octree<512>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
@@ -1209,8 +1343,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         hipLaunchKernelGGL(k_octree<2048>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
                            e->d_keys, e->d_knode, e->d_sel, e->d_sel_cnt, status);
     if (prof) hipEventRecord(ev[3], s);
-    hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, e->d_pyr, e->d_blur, G,
-                       e->d_tiles, e->blurw);
+    hipStreamWaitEvent(s, e->ev_blur, 0);   // join
     if (prof) hipEventRecord(ev[4], s);
     hipLaunchKernelGGL(k_orient_describe, dim3((G.kp_cap_total + 3) / 4, batch), dim3(256), 0, s, e->d_pyr, e->d_blur,
                        G, e->d_sel, e->d_sel_cnt, e->d_disc, e->d_pattern, d_kps, d_desc, cap, d_n, status);
@@ -1274,6 +1407,13 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
         return ORBHIP_E_HIP;
     }
     e->stream = e->own_stream;
+    if (hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming) != hipSuccess) {
+        set_error("aux stream/event creation failed");
+        orbhip_extractor_destroy(e);
+        return ORBHIP_E_HIP;
+    }
     // disc offsets in the reference's traversal order (order is irrelevant for integer sums)
     DiscTab dt; memset(&dt, 0, sizeof(dt));   // padding entries (u = v = 0) contribute 0 to both moments
     int nd = 0;
@@ -1302,6 +1442,9 @@ void orbhip_extractor_destroy(orbhip_extractor *e)
     free_batch(e);
     hipFree(e->d_disc); hipFree(e->d_pattern); hipFree(e->d_img); hipFree(e->d_okp); hipFree(e->d_odesc); hipFree(e->d_on);
     for (hipEvent_t v : e->ev) hipEventDestroy(v);
+    if (e->aux_stream) { hipStreamSynchronize(e->aux_stream); hipStreamDestroy(e->aux_stream); }
+    if (e->ev_pyr) hipEventDestroy(e->ev_pyr);
+    if (e->ev_blur) hipEventDestroy(e->ev_blur);
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -1504,7 +1647,7 @@ int orbhip_extractor_set_profiling(orbhip_extractor *e, int on)
     if (!e) return ORBHIP_E_ARG;
     ORBHIP_HIP_CHECK(hipSetDevice(e->device));
     if (on && e->ev.empty()) {
-        e->ev.resize((size_t)orbhip_extractor::kProfRing * 6);
+        e->ev.resize((size_t)orbhip_extractor::kProfRing * orbhip_extractor::kProfEv);
         for (auto &v : e->ev) ORBHIP_HIP_CHECK(hipEventCreate(&v));
     }
     e->profiling = on != 0;
@@ -1519,16 +1662,16 @@ int orbhip_extractor_stage_times(orbhip_extractor *e, float us[6])
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
     const long n = std::min<long>(e->prof_calls, orbhip_extractor::kProfRing);
     double acc[6] = {0, 0, 0, 0, 0, 0};
+    // stage -> (begin, end) event of the set: pyramid, fast, octree on the main stream; blur on the
+    // auxiliary stream (concurrent with fast + octree); describe after the join; whole call
+    static const int span[6][2] = {{0, 1}, {1, 2}, {2, 3}, {6, 7}, {4, 5}, {0, 5}};
     for (long c = 0; c < n; ++c) {
-        hipEvent_t *ev = &e->ev[(size_t)c * 6];
-        for (int i = 0; i < 5; ++i) {
+        hipEvent_t *ev = &e->ev[(size_t)c * orbhip_extractor::kProfEv];
+        for (int i = 0; i < 6; ++i) {
             float ms = 0;
-            ORBHIP_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            ORBHIP_HIP_CHECK(hipEventElapsedTime(&ms, ev[span[i][0]], ev[span[i][1]]));
             acc[i] += ms * 1000.0;
         }
-        float ms = 0;
-        ORBHIP_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[5]));
-        acc[5] += ms * 1000.0;
     }
     for (int i = 0; i < 6; ++i) us[i] = (float)(acc[i] / n);
     return ORBHIP_OK;

@@ -8,6 +8,12 @@ namespace orbhip {
 struct BlurW { int w[7]; };
 struct TileDesc { short level, tx, ty, pad; };
 constexpr int kBlurTW = 64, kBlurTH = 58;
+// LDS geometry of k_fast_cells, derived on the host from the largest cell of the image size
+struct FastLds {
+    int strideW;      // row stride in dwords (odd): 1 margin dword + staged dwords + 1 spare
+    int div_magic;    // (i * div_magic) >> 20 == i / strideW for i < 8192
+    int img_words, score_words, list_words;
+};
 struct DiscTab { unsigned short uv[768]; };  // 749 disc offsets (u | v << 8), zero padded to 12 x 64
 }  // namespace orbhip
 
@@ -21,7 +27,10 @@ struct orbhip_extractor {
     orbhip::BlurW blurw;
     hipStream_t stream = nullptr;       // stream every launch of this handle goes to
     hipStream_t own_stream = nullptr;   // created with the handle; `stream` may be re-pointed
-    // profiling: ring of event sets (6 events per extract call), averaged on read-out
+    hipStream_t aux_stream = nullptr;   // blur runs here, concurrently with FAST + octree
+    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;   // fork/join of the aux stream
+    // profiling: ring of event sets (kProfEv events per extract call), averaged on read-out
+    static constexpr int kProfEv = 8;
     static constexpr int kProfRing = 256;
     std::vector<hipEvent_t> ev;         // kProfRing * 6, created lazily
     bool profiling = false;
@@ -33,7 +42,8 @@ struct orbhip_extractor {
     std::vector<orbhip::CellDesc> cells;
     std::vector<orbhip::TileDesc> tiles;
     int octree_maxn = 512;
-    int fast_lds_words[4] = {0, 0, 0, 0};   // k_fast_cells dynamic LDS: image, score map, list, finals
+    orbhip::FastLds fast_lds;   // k_fast_cells dynamic LDS carve-up
+    int fast_lds_bytes = 0;
     orbhip::CellDesc *d_cells = nullptr;
     orbhip::TileDesc *d_tiles = nullptr;
     short *d_tabs = nullptr;
