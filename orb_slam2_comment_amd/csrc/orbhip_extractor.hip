@@ -1441,6 +1441,8 @@ void orbhip_extractor_destroy(orbhip_extractor *e)
     free_geometry(e);
     free_batch(e);
     hipFree(e->d_disc); hipFree(e->d_pattern); hipFree(e->d_img); hipFree(e->d_okp); hipFree(e->d_odesc); hipFree(e->d_on);
+    if (e->h_in) hipHostFree(e->h_in);
+    if (e->h_out) hipHostFree(e->h_out);
     for (hipEvent_t v : e->ev) hipEventDestroy(v);
     if (e->aux_stream) { hipStreamSynchronize(e->aux_stream); hipStreamDestroy(e->aux_stream); }
     if (e->ev_pyr) hipEventDestroy(e->ev_pyr);
@@ -1520,36 +1522,59 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
         ORBHIP_HIP_CHECK(hipMalloc(&e->d_img, img_bytes));
         e->d_img_bytes = img_bytes;
     }
-    if (cap > e->out_cap || batch > e->out_batch) {
+    if ((size_t)cap * batch > e->out_slots || batch > e->out_batch) {
         hipFree(e->d_okp); hipFree(e->d_odesc); hipFree(e->d_on);
         e->d_okp = nullptr; e->d_odesc = nullptr; e->d_on = nullptr;
-        int oc = std::max(cap, e->out_cap), ob = std::max(batch, e->out_batch);
-        ORBHIP_HIP_CHECK(hipMalloc(&e->d_okp, (size_t)ob * oc * sizeof(orbhip_keypoint)));
-        ORBHIP_HIP_CHECK(hipMalloc(&e->d_odesc, (size_t)ob * oc * 32));
+        e->out_slots = 0; e->out_batch = 0;
+        const size_t slots = std::max((size_t)cap * batch, e->out_slots);
+        const int ob = std::max(batch, e->out_batch);
+        ORBHIP_HIP_CHECK(hipMalloc(&e->d_okp, slots * sizeof(orbhip_keypoint)));
+        ORBHIP_HIP_CHECK(hipMalloc(&e->d_odesc, slots * 32));
         ORBHIP_HIP_CHECK(hipMalloc(&e->d_on, (size_t)ob * sizeof(int)));
-        e->out_cap = oc; e->out_batch = ob;
+        e->out_slots = slots; e->out_batch = ob;
     }
-    for (int b = 0; b < batch; ++b)
-        ORBHIP_HIP_CHECK(hipMemcpy2DAsync(e->d_img + (size_t)b * rows * cols, cols, images + b * frame_stride, stride,
-                                          cols, rows, hipMemcpyHostToDevice, e->stream));
+    // host -> pinned staging (row copies on the CPU) -> one DMA
+    if (img_bytes > e->h_in_bytes) {
+        if (e->h_in) hipHostFree(e->h_in);
+        e->h_in = nullptr; e->h_in_bytes = 0;
+        ORBHIP_HIP_CHECK(hipHostMalloc((void **)&e->h_in, img_bytes, hipHostMallocDefault));
+        e->h_in_bytes = img_bytes;
+    }
+    const size_t out_bytes = (size_t)batch * (2 * sizeof(int) + (size_t)cap * (sizeof(orbhip_keypoint) + 32));
+    if (out_bytes > e->h_out_bytes) {
+        if (e->h_out) hipHostFree(e->h_out);
+        e->h_out = nullptr; e->h_out_bytes = 0;
+        ORBHIP_HIP_CHECK(hipHostMalloc((void **)&e->h_out, out_bytes, hipHostMallocDefault));
+        e->h_out_bytes = out_bytes;
+    }
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));   // the staging buffer of the previous call is free
+    for (int b = 0; b < batch; ++b) {
+        const uint8_t *src = images + b * frame_stride;
+        uint8_t *dst = e->h_in + (size_t)b * rows * cols;
+        if (stride == cols) memcpy(dst, src, (size_t)rows * cols);
+        else for (int r = 0; r < rows; ++r) memcpy(dst + (size_t)r * cols, src + (size_t)r * stride, cols);
+    }
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img, e->h_in, img_bytes, hipMemcpyHostToDevice, e->stream));
     rc = ensure_batch(e, batch);
     if (rc) return rc;
     rc = launch_pipeline(e, e->d_img, batch, cols, (size_t)rows * cols, e->d_okp, e->d_odesc, cap, e->d_on, nullptr);
     if (rc) return rc;
-    std::vector<int> st(batch);
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(n, e->d_on, batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(st.data(), e->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    int *h_n = reinterpret_cast<int *>(e->h_out), *h_st = h_n + batch;
+    orbhip_keypoint *h_kp = reinterpret_cast<orbhip_keypoint *>(h_st + batch);
+    uint8_t *h_desc = reinterpret_cast<uint8_t *>(h_kp + (size_t)batch * cap);
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_n, e->d_on, batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_st, e->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_kp, e->d_okp, (size_t)batch * cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, e->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_desc, e->d_odesc, (size_t)batch * cap * 32, hipMemcpyDeviceToHost, e->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
     for (int b = 0; b < batch; ++b) {
-        if (st[b] != 0) { set_error("frame %d: capacity exceeded (cap %d)", b, cap); return ORBHIP_E_CAPACITY; }
+        n[b] = h_n[b];
+        if (h_st[b] != 0) { set_error("frame %d: capacity exceeded (cap %d)", b, cap); return ORBHIP_E_CAPACITY; }
         if (n[b] > 0) {
-            ORBHIP_HIP_CHECK(hipMemcpyAsync(kps + (size_t)b * cap, e->d_okp + (size_t)b * cap, (size_t)n[b] * sizeof(orbhip_keypoint),
-                                            hipMemcpyDeviceToHost, e->stream));
-            ORBHIP_HIP_CHECK(hipMemcpyAsync(desc + (size_t)b * cap * 32, e->d_odesc + (size_t)b * cap * 32, (size_t)n[b] * 32,
-                                            hipMemcpyDeviceToHost, e->stream));
+            memcpy(kps + (size_t)b * cap, h_kp + (size_t)b * cap, (size_t)n[b] * sizeof(orbhip_keypoint));
+            memcpy(desc + (size_t)b * cap * 32, h_desc + (size_t)b * cap * 32, (size_t)n[b] * 32);
         }
     }
-    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
     return ORBHIP_OK;
 }
 

@@ -64,6 +64,10 @@ struct orbhip_extractor {
     // staging for the host-pointer API
     uint8_t *d_img = nullptr; size_t d_img_bytes = 0;
     orbhip_keypoint *d_okp = nullptr; uint8_t *d_odesc = nullptr; int *d_on = nullptr;
-    int out_cap = 0, out_batch = 0;
+    size_t out_slots = 0;   // keypoint slots allocated in d_okp / d_odesc
+    int out_batch = 0;      // entries allocated in d_on
+    // pinned host staging (pageable 2-D copies are an order of magnitude slower than one pinned DMA)
+    uint8_t *h_in = nullptr; size_t h_in_bytes = 0;
+    uint8_t *h_out = nullptr; size_t h_out_bytes = 0;
 };
 

@@ -169,6 +169,12 @@ struct ResolveShared {
     int m12[kResolveMax];                // mode 2: vnMatches12
     unsigned char evbin[kResolveMax];    // rotation-histogram bin of the event of query i (0xff none)
     unsigned short evidx[kResolveMax];   // mode 0: bestIdx2 pushed into rotHist
+    // read-only operands staged once so that the serial loop never waits on HBM
+    float t_angle[kResolveMax];          // train keypoint angle
+    float q_angle[kResolveMax];          // query keypoint angle
+    int q_cnt[kResolveMax];              // candidate count per query (sign = unsorted)
+    unsigned char t_oct[kResolveMax];    // train keypoint octave
+    unsigned char q_obs[kResolveMax];    // query map point observed
     int hist[HISTO_LENGTH];
 };
 
@@ -184,19 +190,23 @@ __device__ __forceinline__ int rot_bin(float a1, float a2)
 
 // First / second usable candidate of a query.  `usable(idx, dist)` is evaluated by every lane.
 template <class Usable>
-__device__ __forceinline__ void pick2(const unsigned long long *list, int c, int lane, Usable usable,
+__device__ __forceinline__ void pick2(const unsigned long long *list, unsigned long long v, int c, int lane, Usable usable,
                                       unsigned long long &k1, unsigned long long &k2)
 {
     k1 = ~0ull; k2 = ~0ull;
-    if (c > 0) {  // sorted, <= 64
-        unsigned long long v = lane < c ? list[lane] : ~0ull;
+    if (c > 0) {  // sorted, <= 64; `v` = list[lane], prefetched by the caller
         bool u = lane < c && usable((int)(v & 0xfffffu), (int)(v >> 32));
         unsigned long long bal = __ballot(u);
-        if (bal) {
-            int l1 = __ffsll((long long)bal) - 1;
-            k1 = __shfl(v, l1, 64);
+        if (bal) {   // the winning lanes are wave-uniform: v_readlane, not a ds_bpermute round trip
+            const int l1 = __ffsll((long long)bal) - 1;
+            k1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l1) << 32) |
+                 (unsigned)__builtin_amdgcn_readlane((int)v, l1);
             bal &= bal - 1;
-            if (bal) { int l2 = __ffsll((long long)bal) - 1; k2 = __shfl(v, l2, 64); }
+            if (bal) {
+                const int l2 = __ffsll((long long)bal) - 1;
+                k2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l2) << 32) |
+                     (unsigned)__builtin_amdgcn_readlane((int)v, l2);
+            }
         }
     } else if (c < 0) {  // unsorted: two masked min-reductions
         c = -c;
@@ -236,33 +246,50 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
                                                 const uint8_t *__restrict__ taken_in, float nnratio,
                                                 int check_ori, int *__restrict__ out, int *__restrict__ out_n)
 {
-    __shared__ ResolveShared S;
+    extern __shared__ unsigned char resolve_lds[];
+    ResolveShared &S = *reinterpret_cast<ResolveShared *>(resolve_lds);
     const int lane = threadIdx.x;
     const int n = F.n;
     for (int i = lane; i < n; i += 64) {
         S.block[i] = (mode == 2) ? 0xffff : (unsigned short)(taken_in ? taken_in[i] != 0 : 0);
         S.assign[i] = -1;
+        S.t_angle[i] = F.keys[i].angle;
+        S.t_oct[i] = (unsigned char)F.keys[i].octave;
     }
-    for (int i = lane; i < nq; i += 64) { S.evbin[i] = 0xff; if (mode == 2) S.m12[i] = -1; }
+    for (int i = lane; i < nq; i += 64) {
+        S.evbin[i] = 0xff;
+        if (mode == 2) S.m12[i] = -1;
+        S.q_cnt[i] = cnt[i];
+        S.q_angle[i] = (mode == 2) ? qkeys[i].angle : q[i].angle;
+        S.q_obs[i] = (unsigned char)(mode == 2 ? 0 : (q[i].observed != 0));
+    }
     if (lane < HISTO_LENGTH) S.hist[lane] = 0;
     __syncthreads();
     int nmatches = 0;
+    // software prefetch: the list head of query i+1 is in flight while query i is resolved
+    int c_next = nq > 0 ? S.q_cnt[0] : 0;
+    unsigned long long v_next = (c_next > 0 && lane < c_next) ? cand[lane] : ~0ull;
     for (int i = 0; i < nq; ++i) {
-        const int c = cnt[i];
+        const int c = c_next;
+        const unsigned long long v = v_next;
+        if (i + 1 < nq) {
+            c_next = S.q_cnt[i + 1];
+            v_next = (c_next > 0 && lane < c_next) ? cand[(size_t)(i + 1) * stride + lane] : ~0ull;
+        }
         if (c == 0) continue;
         const unsigned long long *list = cand + (size_t)i * stride;
         unsigned long long k1, k2;
-        if (mode == 2) pick2(list, c, lane, [&](int idx, int dist) { return !((int)S.block[idx] <= dist); }, k1, k2);
-        else pick2(list, c, lane, [&](int idx, int) { return S.block[idx] == 0; }, k1, k2);
+        if (mode == 2) pick2(list, v, c, lane, [&](int idx, int dist) { return !((int)S.block[idx] <= dist); }, k1, k2);
+        else pick2(list, v, c, lane, [&](int idx, int) { return S.block[idx] == 0; }, k1, k2);
         if (k1 == ~0ull) continue;
         const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xfffffu);
         if (mode == 0) {
             if (bestDist <= TH_HIGH) {
                 if (lane == 0) {
                     S.assign[bestIdx] = i;
-                    S.block[bestIdx] = (unsigned short)(q[i].observed != 0);
+                    S.block[bestIdx] = (unsigned short)S.q_obs[i];
                     if (check_ori) {
-                        int bin = rot_bin(q[i].angle, F.keys[bestIdx].angle);
+                        int bin = rot_bin(S.q_angle[i], S.t_angle[bestIdx]);
                         S.hist[bin]++;
                         S.evbin[i] = (unsigned char)bin;
                         S.evidx[i] = (unsigned short)bestIdx;
@@ -273,12 +300,12 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
         } else if (mode == 1) {
             if (bestDist <= TH_HIGH) {
                 const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
-                const int bestLevel = F.keys[bestIdx].octave;
-                const int bestLevel2 = k2 == ~0ull ? -1 : F.keys[(int)(k2 & 0xfffffu)].octave;
+                const int bestLevel = S.t_oct[bestIdx];
+                const int bestLevel2 = k2 == ~0ull ? -1 : (int)S.t_oct[(int)(k2 & 0xfffffu)];
                 if (!(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2))) {
                     if (lane == 0) {
                         S.assign[bestIdx] = i;
-                        S.block[bestIdx] = (unsigned short)(q[i].observed != 0);
+                        S.block[bestIdx] = (unsigned short)S.q_obs[i];
                     }
                     nmatches++;
                 }
@@ -296,7 +323,7 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
                         S.assign[bestIdx] = i;
                         S.block[bestIdx] = (unsigned short)bestDist;
                         if (check_ori) {
-                            int bin = rot_bin(qkeys[i].angle, F.keys[bestIdx].angle);
+                            int bin = rot_bin(S.q_angle[i], S.t_angle[bestIdx]);
                             S.hist[bin]++;
                             S.evbin[i] = (unsigned char)bin;
                         }
@@ -305,7 +332,9 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
                 }
             }
         }
-        __syncthreads();  // single wave: orders lane 0's LDS writes before the next query reads them
+        // single wavefront: DS operations execute in issue order, so the next query's LDS reads see lane 0's
+        // writes; no s_barrier / vmcnt(0) here -- it would drain the prefetch of the next list head
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     if (check_ori && mode != 1) {
@@ -330,6 +359,128 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
     if (mode == 2) for (int i = lane; i < nq; i += 64) out[i] = S.m12[i];
     else for (int i = lane; i < n; i += 64) out[i] = S.assign[i];
     if (lane == 0) *out_n = nmatches;
+}
+
+// ---- parallel resolve for the two SearchByProjection overloads (modes 0 and 1) ------------------
+// The sequential reference loop is the unique solution of
+//   choice(i) = first candidate of query i (in (distance, visiting order)) that is neither taken on entry
+//               nor chosen by an accepted, observed query j < i,
+// so it can be found by fixed-point iteration: every round all queries re-pick in parallel against the
+// owners (smallest accepted observed query per slot) of the previous round; query i is final once all
+// j < i are, so at most nq+1 rounds are needed and typically 3-5.  One workgroup, state in LDS.
+struct ResolveParShared {
+    int owner[2][kResolveMax];           // smallest accepted+observed query that picks the slot (ping-pong)
+    short choice[kResolveMax];           // slot picked by query i, -1 if none accepted
+    float t_angle[kResolveMax], q_angle[kResolveMax];
+    unsigned char t_oct[kResolveMax], q_obs[kResolveMax], taken[kResolveMax], evbin[kResolveMax];
+    int hist[HISTO_LENGTH];
+    int changed, nacc, ncull;
+};
+
+__global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, const orbhip_query *__restrict__ q, int nq,
+                                                      const unsigned long long *__restrict__ cand,
+                                                      const int *__restrict__ cnt, int stride,
+                                                      const uint8_t *__restrict__ taken_in, float nnratio,
+                                                      int check_ori, int *__restrict__ out, int *__restrict__ out_n)
+{
+    extern __shared__ unsigned char resolve_lds[];
+    ResolveParShared &S = *reinterpret_cast<ResolveParShared *>(resolve_lds);
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int n = F.n;
+    for (int i = tid; i < n; i += T) {
+        S.owner[0][i] = INT_MAX;
+        S.taken[i] = (unsigned char)(taken_in ? taken_in[i] != 0 : 0);
+        S.t_angle[i] = F.keys[i].angle;
+        S.t_oct[i] = (unsigned char)F.keys[i].octave;
+    }
+    for (int i = tid; i < nq; i += T) {
+        S.choice[i] = -2;   // "not evaluated yet"
+        S.q_angle[i] = q[i].angle;
+        S.q_obs[i] = (unsigned char)(q[i].observed != 0);
+        S.evbin[i] = 0xff;
+    }
+    if (tid < HISTO_LENGTH) S.hist[tid] = 0;
+    if (tid == 0) { S.nacc = 0; S.ncull = 0; }
+    __syncthreads();
+    int cur = 0;
+    for (int round = 0; round <= nq + 1; ++round) {
+        if (tid == 0) S.changed = 0;
+        for (int c = tid; c < n; c += T) S.owner[cur ^ 1][c] = INT_MAX;
+        __syncthreads();
+        for (int i = tid; i < nq; i += T) {
+            const int c = cnt[i];
+            int newc = -1;
+            if (c != 0) {
+                const unsigned long long *list = cand + (size_t)i * stride;
+                unsigned long long k1 = ~0ull, k2 = ~0ull;
+                if (c > 0) {   // sorted: walk until two usable candidates are found
+                    for (int e = 0; e < c; ++e) {
+                        const unsigned long long v = list[e];
+                        const int idx = (int)(v & 0xfffffu);
+                        if (S.taken[idx] || S.owner[cur][idx] < i) continue;
+                        if (k1 == ~0ull) { k1 = v; if (mode == 0) break; }
+                        else { k2 = v; break; }
+                    }
+                } else {       // unsorted: smallest and second smallest usable key
+                    for (int e = 0; e < -c; ++e) {
+                        const unsigned long long v = list[e];
+                        const int idx = (int)(v & 0xfffffu);
+                        if (S.taken[idx] || S.owner[cur][idx] < i) continue;
+                        if (v < k1) { k2 = k1; k1 = v; } else if (v < k2) k2 = v;
+                    }
+                }
+                if (k1 != ~0ull) {
+                    const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xfffffu);
+                    bool acc = bestDist <= TH_HIGH;
+                    if (acc && mode == 1) {
+                        const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
+                        const int bestLevel = S.t_oct[bestIdx];
+                        const int bestLevel2 = k2 == ~0ull ? -1 : (int)S.t_oct[(int)(k2 & 0xfffffu)];
+                        if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) acc = false;
+                    }
+                    if (acc) newc = bestIdx;
+                }
+            }
+            if (newc != S.choice[i]) { S.choice[i] = (short)newc; S.changed = 1; }
+            if (newc >= 0 && S.q_obs[i]) atomicMin(&S.owner[cur ^ 1][newc], i);
+        }
+        __syncthreads();
+        cur ^= 1;
+        const int changed = S.changed;
+        __syncthreads();
+        if (!changed) break;
+    }
+    // ---- outputs: assign[slot] = last accepted query that picked it; rotation-histogram cull (mode 0) ----
+    int *assign = S.owner[cur ^ 1];   // reuse
+    for (int c = tid; c < n; c += T) assign[c] = -1;
+    __syncthreads();
+    int acc_local = 0;
+    for (int i = tid; i < nq; i += T) {
+        const int c = S.choice[i];
+        if (c < 0) continue;
+        ++acc_local;
+        atomicMax(&assign[c], i);
+        if (mode == 0 && check_ori) {
+            const int bin = rot_bin(S.q_angle[i], S.t_angle[c]);
+            atomicAdd(&S.hist[bin], 1);
+            S.evbin[i] = (unsigned char)bin;
+        }
+    }
+    if (acc_local) atomicAdd(&S.nacc, acc_local);
+    __syncthreads();
+    if (mode == 0 && check_ori) {
+        int ind1, ind2, ind3;
+        three_maxima(S.hist, ind1, ind2, ind3);
+        int cull = 0;
+        for (int i = tid; i < nq; i += T) {
+            const int b = S.evbin[i];
+            if (b != 0xff && b != ind1 && b != ind2 && b != ind3) { assign[S.choice[i]] = -1; ++cull; }
+        }
+        if (cull) atomicAdd(&S.ncull, cull);
+        __syncthreads();
+    }
+    for (int c = tid; c < n; c += T) out[c] = assign[c];
+    if (tid == 0) *out_n = S.nacc - S.ncull;
 }
 
 // ---- DescriptorDistance, batched (ORBmatcher.cc:1647-1663) --------------------------------
@@ -528,6 +679,24 @@ struct orbhip_matcher {
     // grow-only device scratch
     void *buf[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool lds_attr_set = false;
+    // pinned host staging: all inputs of a call travel in one DMA, all outputs in one
+    uint8_t *h_stage = nullptr; size_t h_stage_bytes = 0;
+    uint8_t *h_out = nullptr; size_t h_out_bytes = 0;
+};
+
+static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct Stage {
+    uint8_t *h, *d;
+    size_t off;
+    void *put(const void *src, size_t bytes)
+    {
+        void *dev = d + off;
+        if (bytes) memcpy(h + off, src, bytes);
+        off += al256(bytes);
+        return dev;
+    }
 };
 
 static int scratch(orbhip_matcher *m, int slot, size_t bytes, void **out)
@@ -546,26 +715,36 @@ static int scratch(orbhip_matcher *m, int slot, size_t bytes, void **out)
 
 enum { S_KEYS = 0, S_DESC, S_UR, S_ORD, S_Q, S_QDESC, S_CAND, S_CNT, S_TAKEN, S_OUT, S_QKEYS, S_MISC };
 
-static int upload_frame(orbhip_matcher *m, const orbhip_frame_view *f, DevFrame *D, uint32_t **d_ord)
+static int stage_begin(orbhip_matcher *m, size_t total, Stage *st)
 {
-    void *p;
-    int rc;
-    const size_t n = (size_t)std::max(f->n, 1);
-    if ((rc = scratch(m, S_KEYS, n * sizeof(orbhip_keypoint), &p))) return rc;
-    D->keys = (const orbhip_keypoint *)p;
-    if ((rc = scratch(m, S_DESC, n * 32, &p))) return rc;
-    D->desc = (const uint8_t *)p;
-    D->u_right = nullptr;
-    if (f->u_right) { if ((rc = scratch(m, S_UR, n * sizeof(float), &p))) return rc; D->u_right = (const float *)p; }
-    if ((rc = scratch(m, S_ORD, n * sizeof(uint32_t), &p))) return rc;
-    *d_ord = (uint32_t *)p;
-    D->n = f->n; D->min_x = f->min_x; D->min_y = f->min_y; D->inv_w = f->grid_inv_w; D->inv_h = f->grid_inv_h;
-    if (f->n > 0) {
-        ORBHIP_HIP_CHECK(hipMemcpyAsync((void *)D->keys, f->keys, f->n * sizeof(orbhip_keypoint), hipMemcpyHostToDevice, m->stream));
-        ORBHIP_HIP_CHECK(hipMemcpyAsync((void *)D->desc, f->desc, (size_t)f->n * 32, hipMemcpyHostToDevice, m->stream));
-        if (f->u_right) ORBHIP_HIP_CHECK(hipMemcpyAsync((void *)D->u_right, f->u_right, f->n * sizeof(float), hipMemcpyHostToDevice, m->stream));
-        hipLaunchKernelGGL(k_grid_order, dim3((f->n + 255) / 256), dim3(256), 0, m->stream, *D, *d_ord);
+    total = al256(total) + 256;
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));   // previous call's staging is free
+    if (total > m->h_stage_bytes) {
+        if (m->h_stage) hipHostFree(m->h_stage);
+        m->h_stage = nullptr; m->h_stage_bytes = 0;
+        ORBHIP_HIP_CHECK(hipHostMalloc((void **)&m->h_stage, total, hipHostMallocDefault));
+        m->h_stage_bytes = total;
     }
+    void *d;
+    int rc = scratch(m, S_MISC, total, &d);
+    if (rc) return rc;
+    st->h = m->h_stage; st->d = (uint8_t *)d; st->off = 0;
+    return ORBHIP_OK;
+}
+static int stage_commit(orbhip_matcher *m, Stage *st)
+{
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(st->d, st->h, st->off, hipMemcpyHostToDevice, m->stream));
+    return ORBHIP_OK;
+}
+static int out_buffer(orbhip_matcher *m, size_t bytes, uint8_t **h)
+{
+    if (bytes > m->h_out_bytes) {
+        if (m->h_out) hipHostFree(m->h_out);
+        m->h_out = nullptr; m->h_out_bytes = 0;
+        ORBHIP_HIP_CHECK(hipHostMalloc((void **)&m->h_out, bytes, hipHostMallocDefault));
+        m->h_out_bytes = bytes;
+    }
+    *h = m->h_out;
     return ORBHIP_OK;
 }
 
@@ -575,22 +754,32 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
                       float nnratio, int check_ori, int32_t *out, int nout, int *nmatches)
 {
     ORBHIP_HIP_CHECK(hipSetDevice(m->device));
-    if (train->n > kResolveMax || nq > kResolveMax || train->n >= (1 << 20)) {
+    if (train->n > kResolveMax || nq > kResolveMax) {
         set_error("matcher: %d train / %d query keypoints exceed the LDS-resident limit %d", train->n, nq, kResolveMax);
         return ORBHIP_E_CAPACITY;
     }
     for (int i = 0; i < nout; ++i) out[i] = -1;
     *nmatches = 0;
     if (nq == 0 || train->n == 0) return ORBHIP_OK;
-    DevFrame D;
-    uint32_t *d_ord;
+    const size_t n = (size_t)train->n;
+    Stage st;
     int rc;
-    if ((rc = upload_frame(m, train, &D, &d_ord))) return rc;
+    if ((rc = stage_begin(m, al256(n * sizeof(orbhip_keypoint)) + al256(n * 32) + al256(n * 4) + al256(n) +
+                                 al256((size_t)nq * sizeof(orbhip_query)) + al256((size_t)nq * 32) +
+                                 al256((size_t)nq * sizeof(orbhip_keypoint)), &st))) return rc;
+    DevFrame D;
+    D.n = train->n; D.min_x = train->min_x; D.min_y = train->min_y; D.inv_w = train->grid_inv_w; D.inv_h = train->grid_inv_h;
+    D.keys = (const orbhip_keypoint *)st.put(train->keys, n * sizeof(orbhip_keypoint));
+    D.desc = (const uint8_t *)st.put(train->desc, n * 32);
+    D.u_right = train->u_right ? (const float *)st.put(train->u_right, n * sizeof(float)) : nullptr;
+    const uint8_t *d_taken = taken ? (const uint8_t *)st.put(taken, n) : nullptr;
+    const orbhip_query *d_q = (const orbhip_query *)st.put(q, (size_t)nq * sizeof(orbhip_query));
+    const uint8_t *d_qdesc = (const uint8_t *)st.put(qdesc, (size_t)nq * 32);
+    const orbhip_keypoint *d_qkeys = qkeys ? (const orbhip_keypoint *)st.put(qkeys, (size_t)nq * sizeof(orbhip_keypoint)) : nullptr;
+    if ((rc = stage_commit(m, &st))) return rc;
     void *p;
-    if ((rc = scratch(m, S_Q, (size_t)nq * sizeof(orbhip_query), &p))) return rc;
-    orbhip_query *d_q = (orbhip_query *)p;
-    if ((rc = scratch(m, S_QDESC, (size_t)nq * 32, &p))) return rc;
-    uint8_t *d_qdesc = (uint8_t *)p;
+    if ((rc = scratch(m, S_ORD, n * sizeof(uint32_t), &p))) return rc;
+    uint32_t *d_ord = (uint32_t *)p;
     const int stride = (train->n + 1) & ~1;
     if ((rc = scratch(m, S_CAND, (size_t)nq * stride * sizeof(unsigned long long), &p))) return rc;
     unsigned long long *d_cand = (unsigned long long *)p;
@@ -598,30 +787,29 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
     int *d_cnt = (int *)p;
     if ((rc = scratch(m, S_OUT, (size_t)(nout + 1) * sizeof(int), &p))) return rc;
     int *d_out = (int *)p;
-    uint8_t *d_taken = nullptr;
-    if (taken) {
-        if ((rc = scratch(m, S_TAKEN, (size_t)train->n, &p))) return rc;
-        d_taken = (uint8_t *)p;
-        ORBHIP_HIP_CHECK(hipMemcpyAsync(d_taken, taken, train->n, hipMemcpyHostToDevice, m->stream));
-    }
-    orbhip_keypoint *d_qkeys = nullptr;
-    if (qkeys) {
-        if ((rc = scratch(m, S_QKEYS, (size_t)nq * sizeof(orbhip_keypoint), &p))) return rc;
-        d_qkeys = (orbhip_keypoint *)p;
-        ORBHIP_HIP_CHECK(hipMemcpyAsync(d_qkeys, qkeys, (size_t)nq * sizeof(orbhip_keypoint), hipMemcpyHostToDevice, m->stream));
-    }
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_q, q, (size_t)nq * sizeof(orbhip_query), hipMemcpyHostToDevice, m->stream));
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_qdesc, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    uint8_t *h_out;
+    if ((rc = out_buffer(m, (size_t)(nout + 1) * sizeof(int), &h_out))) return rc;
+    hipLaunchKernelGGL(k_grid_order, dim3((train->n + 255) / 256), dim3(256), 0, m->stream, D, d_ord);
     hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_ord, d_q, d_qdesc, nq, d_cand,
                        d_cnt, stride, mode != 2);
-    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, m->stream, mode, D, d_qkeys, d_q, nq, d_cand, d_cnt, stride,
-                       d_taken, nnratio, check_ori, d_out, d_out + nout);
+    if (!m->lds_attr_set) {   // > 64 KB of dynamic LDS needs the opt-in attribute (per device)
+        ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)sizeof(ResolveShared)));
+        ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_par), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)sizeof(ResolveParShared)));
+        m->lds_attr_set = true;
+    }
+    if (mode == 2)   // SearchForInitialization: match stealing depends on the running minimum distance -> serial replay
+        hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(ResolveShared), m->stream, mode, D, d_qkeys, d_q, nq, d_cand,
+                           d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout);
+    else
+        hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), sizeof(ResolveParShared), m->stream, mode, D, d_q, nq, d_cand,
+                           d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout);
     ORBHIP_HIP_CHECK(hipGetLastError());
-    std::vector<int> host(nout + 1);
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(host.data(), d_out, (size_t)(nout + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)(nout + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
-    memcpy(out, host.data(), (size_t)nout * sizeof(int));
-    *nmatches = host[nout];
+    memcpy(out, h_out, (size_t)nout * sizeof(int));
+    *nmatches = reinterpret_cast<const int *>(h_out)[nout];
     return ORBHIP_OK;
 }
 
@@ -653,6 +841,8 @@ void orbhip_matcher_destroy(orbhip_matcher *m)
     hipSetDevice(m->device);
     if (m->stream) hipStreamSynchronize(m->stream);
     for (int i = 0; i < 12; ++i) hipFree(m->buf[i]);
+    if (m->h_stage) hipHostFree(m->h_stage);
+    if (m->h_out) hipHostFree(m->h_out);
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
 }
@@ -752,33 +942,32 @@ int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int
     }
     void *p;
     int rc;
-    if ((rc = scratch(m, S_KEYS, (size_t)nl * sizeof(orbhip_keypoint), &p))) return rc;
-    orbhip_keypoint *d_kl = (orbhip_keypoint *)p;
-    if ((rc = scratch(m, S_DESC, (size_t)nl * 32, &p))) return rc;
-    uint8_t *d_dl = (uint8_t *)p;
-    if ((rc = scratch(m, S_QKEYS, (size_t)nr * sizeof(orbhip_keypoint), &p))) return rc;
-    orbhip_keypoint *d_kr = (orbhip_keypoint *)p;
-    if ((rc = scratch(m, S_QDESC, (size_t)nr * 32, &p))) return rc;
-    uint8_t *d_dr = (uint8_t *)p;
+    Stage st;
+    if ((rc = stage_begin(m, al256((size_t)nl * sizeof(orbhip_keypoint)) + al256((size_t)nl * 32) +
+                                 al256((size_t)nr * sizeof(orbhip_keypoint)) + al256((size_t)nr * 32), &st))) return rc;
+    const orbhip_keypoint *d_kl = (const orbhip_keypoint *)st.put(keys_l, (size_t)nl * sizeof(orbhip_keypoint));
+    const uint8_t *d_dl = (const uint8_t *)st.put(desc_l, (size_t)nl * 32);
+    const orbhip_keypoint *d_kr = (const orbhip_keypoint *)st.put(keys_r, (size_t)nr * sizeof(orbhip_keypoint));
+    const uint8_t *d_dr = (const uint8_t *)st.put(desc_r, (size_t)nr * 32);
+    if ((rc = stage_commit(m, &st))) return rc;
     if ((rc = scratch(m, S_ORD, (size_t)nr * sizeof(int2), &p))) return rc;
     int2 *d_band = (int2 *)p;
-    if ((rc = scratch(m, S_OUT, (size_t)nl * 2 * sizeof(float), &p))) return rc;
+    // outputs contiguous: u_right[nl] | depth[nl] | sad[nl] | n
+    if ((rc = scratch(m, S_OUT, (size_t)(3 * nl + 1) * sizeof(float), &p))) return rc;
     float *d_ur = (float *)p, *d_depth = d_ur + nl;
-    if ((rc = scratch(m, S_CNT, (size_t)(nl + 1) * sizeof(int), &p))) return rc;
-    int *d_sad = (int *)p, *d_n = d_sad + nl;
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_kl, keys_l, (size_t)nl * sizeof(orbhip_keypoint), hipMemcpyHostToDevice, m->stream));
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_dl, desc_l, (size_t)nl * 32, hipMemcpyHostToDevice, m->stream));
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_kr, keys_r, (size_t)nr * sizeof(orbhip_keypoint), hipMemcpyHostToDevice, m->stream));
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(d_dr, desc_r, (size_t)nr * 32, hipMemcpyHostToDevice, m->stream));
+    int *d_sad = (int *)(d_depth + nl), *d_n = d_sad + nl;
+    uint8_t *h_out;
+    if ((rc = out_buffer(m, (size_t)(3 * nl + 1) * sizeof(float), &h_out))) return rc;
     hipLaunchKernelGGL(k_stereo_rows, dim3((nr + 255) / 256), dim3(256), 0, m->stream, d_kr, nr, G, d_band);
     hipLaunchKernelGGL(k_stereo_match, dim3((nl + 3) / 4), dim3(256), 0, m->stream, d_kl, d_dl, nl, d_kr, d_dr, nr, d_band,
                        G, d_ur, d_depth, d_sad);
     hipLaunchKernelGGL(k_stereo_cull, dim3(1), dim3(256), 0, m->stream, nl, d_sad, d_ur, d_depth, d_n);
     ORBHIP_HIP_CHECK(hipGetLastError());
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(u_right, d_ur, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(depth, d_depth, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(nmatches, d_n, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_ur, (size_t)(3 * nl + 1) * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    memcpy(u_right, h_out, (size_t)nl * sizeof(float));
+    memcpy(depth, h_out + (size_t)nl * sizeof(float), (size_t)nl * sizeof(float));
+    *nmatches = reinterpret_cast<const int *>(h_out)[3 * nl];
     return ORBHIP_OK;
 }
 
