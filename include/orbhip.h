@@ -174,6 +174,26 @@ int orbhip_search_by_projection_points(orbhip_matcher *m, const orbhip_frame_vie
                                        const uint8_t *taken, int32_t *assign, float nnratio,
                                        int *nmatches);
 
+/* Device-resident, batched forms of the two SearchByProjection searches: `pairs` independent frame pairs,
+ * asynchronous on the matcher's stream.  Train side in the extractor's output layout: d_kps [pairs][cap]
+ * orbhip_keypoint, d_desc [pairs][cap][32], d_n [pairs] int32; optional d_u_right [pairs][cap] float and
+ * d_taken [pairs][cap] uint8.  Query side: d_q [pairs][qcap] orbhip_query, d_qdesc [pairs][qcap][32],
+ * d_nq [pairs] int32.  The image bounds / grid scale are shared (one camera).  Outputs: d_assign [pairs][cap]
+ * int32 (query index held by each keypoint or -1), d_nmatches [pairs] int32.  cap, qcap <= 4096. */
+int orbhip_search_by_projection_frame_device(orbhip_matcher *m, int pairs, const void *d_kps, const void *d_desc,
+                                             const void *d_n, int cap, const void *d_u_right, const void *d_taken,
+                                             float min_x, float min_y, float grid_inv_w, float grid_inv_h,
+                                             const void *d_q, const void *d_qdesc, const void *d_nq, int qcap,
+                                             int check_ori, void *d_assign, void *d_nmatches);
+int orbhip_search_by_projection_points_device(orbhip_matcher *m, int pairs, const void *d_kps, const void *d_desc,
+                                              const void *d_n, int cap, const void *d_u_right, const void *d_taken,
+                                              float min_x, float min_y, float grid_inv_w, float grid_inv_h,
+                                              const void *d_q, const void *d_qdesc, const void *d_nq, int qcap,
+                                              float nnratio, void *d_assign, void *d_nmatches);
+/* Launch on a caller-owned hipStream_t (NULL: the handle's own stream); wait for the handle's stream. */
+int orbhip_matcher_set_stream(orbhip_matcher *m, void *stream);
+int orbhip_matcher_sync(orbhip_matcher *m);
+
 /* Frame::ComputeStereoMatches.  The image pyramids are the ones left in the two extractor
  * handles by their last extract call (frame indices frame_l / frame_r of those batches), i.e.
  * mpORBextractorLeft/Right->mvImagePyramid.  keys/desc: host buffers (mvKeys, mDescriptors,

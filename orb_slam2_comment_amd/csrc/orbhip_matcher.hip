@@ -32,6 +32,21 @@ struct DevFrame {
     float min_x, min_y, inv_w, inv_h;
 };
 
+// Batched (device-resident) calls: pair p = blockIdx.y uses element strides cap / qcap; the single-pair
+// host path passes zero strides and null count pointers.
+struct Batch {
+    const int *n_dev;    // per-pair train keypoint counts, or null (use F.n)
+    const int *nq_dev;   // per-pair query counts, or null (use the nq argument)
+    int cap, qcap;
+};
+__device__ __forceinline__ void batch_frame(DevFrame &F, const Batch &B, int pair)
+{
+    F.keys += (size_t)pair * B.cap;
+    F.desc += (size_t)pair * B.cap * 32;
+    if (F.u_right) F.u_right += (size_t)pair * B.cap;
+    if (B.n_dev) F.n = min(B.n_dev[pair], B.cap);
+}
+
 __device__ __forceinline__ int hamming256(const uint32_t *a, const uint32_t *b)
 {
     int d = 0;
@@ -60,8 +75,10 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // Visiting order of Frame::GetFeaturesInArea (cell-major ix outer / iy inner, insertion
 // order inside a cell; Frame.cc:350-358) as a sortable key: (posX*48+posY) << 20 | index.
 // Keypoints that PosInGrid rejects (Frame.cc:382-392) are never candidates.
-__global__ void k_grid_order(DevFrame F, uint32_t *__restrict__ ord)
+__global__ void k_grid_order(DevFrame F, uint32_t *__restrict__ ord, Batch B)
 {
+    batch_frame(F, B, blockIdx.y);
+    ord += (size_t)blockIdx.y * B.cap;
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= F.n) return;
     const orbhip_keypoint kp = F.keys[j];
@@ -78,10 +95,18 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const uint32_
                                                        const orbhip_query *__restrict__ q,
                                                        const uint8_t *__restrict__ qdesc, int nq,
                                                        unsigned long long *__restrict__ cand,
-                                                       int *__restrict__ cnt, int stride, int use_ur)
+                                                       int *__restrict__ cnt, int stride, int use_ur, Batch B)
 {
     __shared__ unsigned long long stage[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pair = blockIdx.y;
+    batch_frame(F, B, pair);
+    ord += (size_t)pair * B.cap;
+    q += (size_t)pair * B.qcap;
+    qdesc += (size_t)pair * B.qcap * 32;
+    cand += (size_t)pair * B.qcap * stride;
+    cnt += (size_t)pair * B.qcap;
+    if (B.nq_dev) nq = min(B.nq_dev[pair], B.qcap);
     const int qi = blockIdx.x * 4 + wv;
     if (qi >= nq) return;
     const orbhip_query Q = q[qi];
@@ -381,11 +406,22 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                                                       const unsigned long long *__restrict__ cand,
                                                       const int *__restrict__ cnt, int stride,
                                                       const uint8_t *__restrict__ taken_in, float nnratio,
-                                                      int check_ori, int *__restrict__ out, int *__restrict__ out_n)
+                                                      int check_ori, int *__restrict__ out, int *__restrict__ out_n, Batch B)
 {
     extern __shared__ unsigned char resolve_lds[];
     ResolveParShared &S = *reinterpret_cast<ResolveParShared *>(resolve_lds);
     const int tid = threadIdx.x, T = blockDim.x;
+    {
+        const int pair = blockIdx.x;
+        batch_frame(F, B, pair);
+        q += (size_t)pair * B.qcap;
+        cand += (size_t)pair * B.qcap * stride;
+        cnt += (size_t)pair * B.qcap;
+        if (taken_in) taken_in += (size_t)pair * B.cap;
+        out += (size_t)pair * B.cap;
+        out_n += pair;
+        if (B.nq_dev) nq = min(B.nq_dev[pair], B.qcap);
+    }
     const int n = F.n;
     for (int i = tid; i < n; i += T) {
         S.owner[0][i] = INT_MAX;
@@ -643,13 +679,27 @@ __global__ __launch_bounds__(256) void k_stereo_cull(int nl, const int *__restri
     const int nd = s_nd;
     if (nd == 0) { if (tid == 0) *out_n = 0; return; }
     const int target = nd / 2;
+    // rank counting over an LDS copy of the SAD list (broadcast reads); lists longer than the LDS copy fall
+    // back to reading HBM
+    __shared__ int s_sad[kResolveMax];
+    const bool in_lds = nl <= kResolveMax;
+    if (in_lds) for (int i = tid; i < nl; i += 256) s_sad[i] = sad[i];
+    __syncthreads();
     for (int i = tid; i < nl; i += 256) {
-        const int d = sad[i];
+        const int d = in_lds ? s_sad[i] : sad[i];
         if (d < 0) continue;
         int rank = 0;
-        for (int j = 0; j < nl; ++j) {
-            const int dj = sad[j];
-            rank += (dj >= 0) && (dj < d || (dj == d && j < i));
+        if (in_lds) {
+#pragma unroll 8
+            for (int j = 0; j < nl; ++j) {
+                const int dj = s_sad[j];
+                rank += (dj >= 0) && (dj < d || (dj == d && j < i));
+            }
+        } else {
+            for (int j = 0; j < nl; ++j) {
+                const int dj = sad[j];
+                rank += (dj >= 0) && (dj < d || (dj == d && j < i));
+            }
         }
         if (rank == target) s_med = d;
     }
@@ -675,7 +725,8 @@ using namespace orbhip;
 
 struct orbhip_matcher {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // stream every launch goes to
+    hipStream_t own_stream = nullptr;   // created with the handle
     // grow-only device scratch
     void *buf[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -748,6 +799,18 @@ static int out_buffer(orbhip_matcher *m, size_t bytes, uint8_t **h)
     return ORBHIP_OK;
 }
 
+static int ensure_resolve_attr(orbhip_matcher *m)
+{
+    if (!m->lds_attr_set) {   // > 64 KB of dynamic LDS needs the opt-in attribute (per device)
+        ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)sizeof(ResolveShared)));
+        ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_par), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)sizeof(ResolveParShared)));
+        m->lds_attr_set = true;
+    }
+    return ORBHIP_OK;
+}
+
 // shared driver of the three windowed searches
 static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *train, const orbhip_query *q,
                       const uint8_t *qdesc, const orbhip_keypoint *qkeys, int nq, const uint8_t *taken,
@@ -789,22 +852,17 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
     int *d_out = (int *)p;
     uint8_t *h_out;
     if ((rc = out_buffer(m, (size_t)(nout + 1) * sizeof(int), &h_out))) return rc;
-    hipLaunchKernelGGL(k_grid_order, dim3((train->n + 255) / 256), dim3(256), 0, m->stream, D, d_ord);
+    const Batch one = {nullptr, nullptr, 0, 0};
+    hipLaunchKernelGGL(k_grid_order, dim3((train->n + 255) / 256), dim3(256), 0, m->stream, D, d_ord, one);
     hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_ord, d_q, d_qdesc, nq, d_cand,
-                       d_cnt, stride, mode != 2);
-    if (!m->lds_attr_set) {   // > 64 KB of dynamic LDS needs the opt-in attribute (per device)
-        ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)sizeof(ResolveShared)));
-        ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_par), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)sizeof(ResolveParShared)));
-        m->lds_attr_set = true;
-    }
+                       d_cnt, stride, mode != 2, one);
+    if ((rc = ensure_resolve_attr(m))) return rc;
     if (mode == 2)   // SearchForInitialization: match stealing depends on the running minimum distance -> serial replay
         hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(ResolveShared), m->stream, mode, D, d_qkeys, d_q, nq, d_cand,
                            d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout);
     else
         hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), sizeof(ResolveParShared), m->stream, mode, D, d_q, nq, d_cand,
-                           d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout);
+                           d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout, one);
     ORBHIP_HIP_CHECK(hipGetLastError());
     ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)(nout + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -826,11 +884,12 @@ int orbhip_matcher_create(int device, orbhip_matcher **out)
     orbhip_matcher *m = new (std::nothrow) orbhip_matcher();
     if (!m) return ORBHIP_E_ARG;
     m->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("hipSetDevice/hipStreamCreate failed");
         delete m;
         return ORBHIP_E_HIP;
     }
+    m->stream = m->own_stream;
     *out = m;
     return ORBHIP_OK;
 }
@@ -843,7 +902,7 @@ void orbhip_matcher_destroy(orbhip_matcher *m)
     for (int i = 0; i < 12; ++i) hipFree(m->buf[i]);
     if (m->h_stage) hipHostFree(m->h_stage);
     if (m->h_out) hipHostFree(m->h_out);
-    if (m->stream) hipStreamDestroy(m->stream);
+    if (m->own_stream) hipStreamDestroy(m->own_stream);
     delete m;
 }
 
@@ -909,6 +968,79 @@ int orbhip_search_by_projection_points(orbhip_matcher *m, const orbhip_frame_vie
 {
     if (!m || !f || (nq > 0 && (!q || !qdesc)) || !assign || !nmatches || nq < 0) return ORBHIP_E_ARG;
     return run_search(m, 1, f, q, qdesc, nullptr, nq, taken, nnratio, 0, assign, f->n, nmatches);
+}
+
+static int search_device(orbhip_matcher *m, int mode, int pairs, const void *d_kps, const void *d_desc, const void *d_n,
+                         int cap, const void *d_u_right, const void *d_taken, float min_x, float min_y, float grid_inv_w,
+                         float grid_inv_h, const void *d_q, const void *d_qdesc, const void *d_nq, int qcap, float nnratio,
+                         int check_ori, void *d_assign, void *d_nmatches)
+{
+    if (!m || pairs <= 0 || !d_kps || !d_desc || !d_n || !d_q || !d_qdesc || !d_nq || !d_assign || !d_nmatches || cap <= 0 || qcap <= 0)
+        return ORBHIP_E_ARG;
+    if (cap > kResolveMax || qcap > kResolveMax) {
+        set_error("matcher: cap %d / qcap %d exceed the LDS-resident limit %d", cap, qcap, kResolveMax);
+        return ORBHIP_E_CAPACITY;
+    }
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    void *p;
+    if ((rc = scratch(m, S_ORD, (size_t)pairs * cap * sizeof(uint32_t), &p))) return rc;
+    uint32_t *d_ord = (uint32_t *)p;
+    const int stride = (cap + 1) & ~1;
+    if ((rc = scratch(m, S_CAND, (size_t)pairs * qcap * stride * sizeof(unsigned long long), &p))) return rc;
+    unsigned long long *d_cand = (unsigned long long *)p;
+    if ((rc = scratch(m, S_CNT, (size_t)pairs * qcap * sizeof(int), &p))) return rc;
+    int *d_cnt = (int *)p;
+    if ((rc = ensure_resolve_attr(m))) return rc;
+    DevFrame D;
+    D.n = cap; D.keys = (const orbhip_keypoint *)d_kps; D.desc = (const uint8_t *)d_desc; D.u_right = (const float *)d_u_right;
+    D.min_x = min_x; D.min_y = min_y; D.inv_w = grid_inv_w; D.inv_h = grid_inv_h;
+    const Batch B = {(const int *)d_n, (const int *)d_nq, cap, qcap};
+    hipLaunchKernelGGL(k_grid_order, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, D, d_ord, B);
+    hipLaunchKernelGGL(k_window_search, dim3((qcap + 3) / 4, pairs), dim3(256), 0, m->stream, D, d_ord, (const orbhip_query *)d_q,
+                       (const uint8_t *)d_qdesc, qcap, d_cand, d_cnt, stride, 1, B);
+    hipLaunchKernelGGL(k_resolve_par, dim3(pairs), dim3(1024), sizeof(ResolveParShared), m->stream, mode, D,
+                       (const orbhip_query *)d_q, qcap, d_cand, d_cnt, stride, (const uint8_t *)d_taken, nnratio, check_ori,
+                       (int *)d_assign, (int *)d_nmatches, B);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_search_by_projection_frame_device(orbhip_matcher *m, int pairs, const void *d_kps, const void *d_desc,
+                                             const void *d_n, int cap, const void *d_u_right, const void *d_taken,
+                                             float min_x, float min_y, float grid_inv_w, float grid_inv_h,
+                                             const void *d_q, const void *d_qdesc, const void *d_nq, int qcap,
+                                             int check_ori, void *d_assign, void *d_nmatches)
+{
+    return search_device(m, 0, pairs, d_kps, d_desc, d_n, cap, d_u_right, d_taken, min_x, min_y, grid_inv_w, grid_inv_h, d_q,
+                         d_qdesc, d_nq, qcap, 0.f, check_ori, d_assign, d_nmatches);
+}
+
+int orbhip_search_by_projection_points_device(orbhip_matcher *m, int pairs, const void *d_kps, const void *d_desc,
+                                              const void *d_n, int cap, const void *d_u_right, const void *d_taken,
+                                              float min_x, float min_y, float grid_inv_w, float grid_inv_h,
+                                              const void *d_q, const void *d_qdesc, const void *d_nq, int qcap,
+                                              float nnratio, void *d_assign, void *d_nmatches)
+{
+    return search_device(m, 1, pairs, d_kps, d_desc, d_n, cap, d_u_right, d_taken, min_x, min_y, grid_inv_w, grid_inv_h, d_q,
+                         d_qdesc, d_nq, qcap, nnratio, 0, d_assign, d_nmatches);
+}
+
+int orbhip_matcher_set_stream(orbhip_matcher *m, void *stream)
+{
+    if (!m) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    m->stream = stream ? (hipStream_t)stream : m->own_stream;
+    return ORBHIP_OK;
+}
+
+int orbhip_matcher_sync(orbhip_matcher *m)
+{
+    if (!m) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBHIP_OK;
 }
 
 int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int frame_l, orbhip_extractor *right,

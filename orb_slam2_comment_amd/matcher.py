@@ -115,6 +115,32 @@ class ORBmatcher:
               "orbhip_search_by_projection_points")
         return n.value, out[:F.N].copy()
 
+    # -- device-resident, batched SearchByProjection ---------------------------
+    def set_stream(self, stream):
+        check(self._lib.orbhip_matcher_set_stream(self._h, stream), "orbhip_matcher_set_stream")
+
+    def sync(self):
+        check(self._lib.orbhip_matcher_sync(self._h), "orbhip_matcher_sync")
+
+    def SearchByProjectionFrameDevice(self, pairs, d_kps, d_desc, d_n, cap, bounds, d_q, d_qdesc, d_nq, qcap, d_assign,
+                                      d_nmatches, d_u_right=0, d_taken=0):
+        """All d_* are device pointers (ints).  bounds = (mnMinX, mnMinY, mnMaxX, mnMaxY)."""
+        b = [np.float32(v) for v in bounds]
+        inv_w = np.float32(FRAME_GRID_COLS) / (b[2] - b[0])
+        inv_h = np.float32(FRAME_GRID_ROWS) / (b[3] - b[1])
+        check(self._lib.orbhip_search_by_projection_frame_device(
+            self._h, pairs, d_kps, d_desc, d_n, cap, d_u_right, d_taken, b[0], b[1], inv_w, inv_h, d_q, d_qdesc, d_nq,
+            qcap, int(self.mbCheckOrientation), d_assign, d_nmatches), "orbhip_search_by_projection_frame_device")
+
+    def SearchByProjectionPointsDevice(self, pairs, d_kps, d_desc, d_n, cap, bounds, d_q, d_qdesc, d_nq, qcap, d_assign,
+                                       d_nmatches, d_u_right=0, d_taken=0):
+        b = [np.float32(v) for v in bounds]
+        inv_w = np.float32(FRAME_GRID_COLS) / (b[2] - b[0])
+        inv_h = np.float32(FRAME_GRID_ROWS) / (b[3] - b[1])
+        check(self._lib.orbhip_search_by_projection_points_device(
+            self._h, pairs, d_kps, d_desc, d_n, cap, d_u_right, d_taken, b[0], b[1], inv_w, inv_h, d_q, d_qdesc, d_nq,
+            qcap, self.mfNNratio, d_assign, d_nmatches), "orbhip_search_by_projection_points_device")
+
     # -- Frame::ComputeStereoMatches (src/Frame.cc:466-640) --------------------
     def ComputeStereoMatches(self, extractor_left, extractor_right, keys_l, desc_l, keys_r, desc_r, mbf, mb,
                              frame_l=0, frame_r=0):

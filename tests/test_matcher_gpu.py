@@ -214,3 +214,66 @@ def test_compute_stereo_matches(env, seed, W, H, nf):
     # disparity sanity: uL - uR within the scene's [2, 80] px layers (+- sub-pixel refinement)
     disp = kl["x"][ur > 0] - ur[ur > 0]
     assert np.all(disp >= 0) and np.median(disp) > 2 and np.percentile(disp, 90) < 90   # a few false matches reach maxD
+
+
+def test_device_batched_search_by_projection_equals_host_api(env):
+    """orbhip_search_by_projection_{frame,points}_device over 4 frame pairs straight from the extractor's
+    device outputs == the host-pointer entry points pair by pair (which are checked against the oracle)."""
+    import torch
+    pkg, M, O = env
+    dev = torch.device("cuda:0")
+    B, H, W = 8, 376, 1241
+    frames = np.stack([synth_frame(30 + b // 2, W, H, shift_xy=(3 * (b % 2), b % 2)) for b in range(B)])
+    ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    cap = ext.capacity(H, W)
+    d_img = torch.from_numpy(frames).to(dev)
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.int32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    ext.extract_batch_device(d_img.data_ptr(), B, H, W, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+    ext.sync()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28).copy().view(pkg.KP_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy()
+    n = d_n.cpu().numpy()
+    sf = ext.GetScaleFactors()
+    pairs = B // 2
+    rng = np.random.default_rng(5)
+    q = np.zeros((pairs, cap), pkg.QUERY_DTYPE)
+    qd = np.zeros((pairs, cap, 32), np.uint8)
+    nq = np.zeros(pairs, np.int32)
+    taken = (rng.random((pairs, cap)) < 0.05).astype(np.uint8)
+    ur = np.where(rng.random((pairs, cap)) < 0.5, rng.uniform(5, 1200, (pairs, cap)), -1).astype(np.float32)
+    for p in range(pairs):
+        k0 = kps[2 * p, :n[2 * p]]
+        m0 = len(k0)
+        nq[p] = m0
+        q[p, :m0]["valid"] = rng.random(m0) < 0.9
+        q[p, :m0]["u"] = k0["x"] + 3; q[p, :m0]["v"] = k0["y"] + 1
+        q[p, :m0]["radius"] = 15 * sf[k0["octave"]]
+        q[p, :m0]["min_level"] = k0["octave"] - 1; q[p, :m0]["max_level"] = k0["octave"] + 1
+        q[p, :m0]["ur"] = k0["x"] - 20; q[p, :m0]["angle"] = k0["angle"]
+        q[p, :m0]["observed"] = rng.random(m0) < 0.7
+        qd[p, :m0] = desc[2 * p, :m0]
+    # train side = odd frames: gather them into contiguous [pairs, cap] device tensors
+    t_kps = d_kps[1::2].contiguous(); t_desc = d_desc[1::2].contiguous(); t_n = d_n[1::2].contiguous()
+    t_q = torch.from_numpy(q.view(np.uint8).reshape(pairs, cap, 40).copy()).to(dev)
+    t_qd = torch.from_numpy(qd).to(dev); t_nq = torch.from_numpy(nq).to(dev)
+    t_taken = torch.from_numpy(taken).to(dev); t_ur = torch.from_numpy(ur).to(dev)
+    t_assign = torch.zeros((pairs, cap), dtype=torch.int32, device=dev)
+    t_nm = torch.zeros(pairs, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    bounds = (0.0, 0.0, float(W), float(H))
+    for mode in ("frame", "points"):
+        m = pkg.ORBmatcher(0.8, True)
+        fn = m.SearchByProjectionFrameDevice if mode == "frame" else m.SearchByProjectionPointsDevice
+        fn(pairs, t_kps.data_ptr(), t_desc.data_ptr(), t_n.data_ptr(), cap, bounds, t_q.data_ptr(), t_qd.data_ptr(),
+           t_nq.data_ptr(), cap, t_assign.data_ptr(), t_nm.data_ptr(), d_u_right=t_ur.data_ptr(), d_taken=t_taken.data_ptr())
+        m.sync()
+        assign = t_assign.cpu().numpy(); nm = t_nm.cpu().numpy()
+        for p in range(pairs):
+            n1 = int(n[2 * p + 1])
+            view = pkg.FrameView(kps[2 * p + 1, :n1], desc[2 * p + 1, :n1], sf, bounds, ur[p, :n1])
+            host = m.SearchByProjectionFrame if mode == "frame" else m.SearchByProjectionPoints
+            hn, hassign = host(view, q[p, :nq[p]], qd[p, :nq[p]], taken[p, :n1])
+            assert hn == nm[p] and np.array_equal(hassign, assign[p, :n1]), (mode, p)
+            assert hn > 100
