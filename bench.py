@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-match", action="store_true", help="skip the secondary extract+match measurement")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL; default) or gloo (rehearsal of the multi-rank control flow on one GPU: "
                          "all ranks share cuda:0 and the gather goes through host memory)")
@@ -114,14 +115,16 @@ def main():
     from orb_slam2_comment_amd.synth import synth_frame
 
     B = args.frames_per_gpu
-    # global batch of B*world frames; rank r owns frames r, r+world, ... (16 distinct seeds, tiled)
+    # global batch of B*world frames; rank r owns frames r, r+world, ...  Local frames come in (t, t+1) pairs of
+    # one scene (8 scenes, the second view translated by 3 px) so that the secondary extract+match measurement
+    # matches real consecutive views; the extractor sees 16 distinct images per rank.
     mine = shard_indices(B * world, rank, world)
     uniq = {}
-    for gidx in mine:
-        s = 1 + gidx % 16
-        if s not in uniq:
-            uniq[s] = synth_frame(s, W, H)
-    frames = np.stack([uniq[1 + gidx % 16] for gidx in mine])
+    for li in range(len(mine)):
+        key = (1 + (li // 2) % 8, li % 2)
+        if key not in uniq:
+            uniq[key] = synth_frame(key[0], W, H, shift_xy=(3 * key[1], 0))
+    frames = np.stack([uniq[(1 + (li // 2) % 8, li % 2)] for li in range(len(mine))])
     d_img = torch.from_numpy(frames).to(dev)
 
     Hn = max(1, args.handles)
@@ -188,6 +191,60 @@ def main():
     n_host = d_n.cpu().numpy()
     assert int(d_st.abs().sum().item()) == 0 and n_host.min() > 0, "extraction failed"
 
+    # ---- secondary measurement (never `value`): extract + SearchByProjection, all on the device --------
+    # configs[2]-style tracking step: every odd frame of the batch is matched against its predecessor
+    # (ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th=15), src/Tracking.cc:880-885) with queries
+    # built on the GPU from the predecessor's keypoints (synthetic 3-px motion), 32 pairs per step.
+    match_info = None
+    if not args.no_match and world == 1:
+        from orb_slam2_comment_amd import ORBmatcher
+        mt = ORBmatcher(0.9, True, device=local_rank)
+        cur = torch.cuda.current_stream(dev)
+        mt.set_stream(cur.cuda_stream)
+        pairs = B // 2
+        sf_t = torch.from_numpy(ext.GetScaleFactors()).to(dev)
+        ar = torch.arange(cap, device=dev)[None, :]
+        t_assign = torch.zeros((pairs, cap), dtype=torch.int32, device=dev)
+        t_nm = torch.zeros(pairs, dtype=torch.int32, device=dev)
+        i32 = torch.int32
+
+        def match_step():
+            step()
+            for st in streams:
+                cur.wait_stream(st)
+            last_k, last_d, last_n = d_kps[0::2], d_desc[0::2].contiguous(), d_n[0::2].contiguous()
+            kf = last_k.view(torch.float32)
+            octv = last_k[..., 5].clamp(0, NLEVELS - 1)
+            valid = (ar < last_n[:, None]).to(i32)
+            u = (kf[..., 0] + 3.0).contiguous().view(i32)
+            v = kf[..., 1].contiguous().view(i32)
+            rad = (15.0 * sf_t[octv.long()]).contiguous().view(i32)
+            zero = torch.zeros_like(valid)
+            q = torch.stack([valid, u, v, rad, octv - 1, octv + 1, zero, octv, kf[..., 3].contiguous().view(i32),
+                             torch.ones_like(valid)], dim=-1).contiguous()
+            ck, cd, cn = d_kps[1::2].contiguous(), d_desc[1::2].contiguous(), d_n[1::2].contiguous()
+            mt.SearchByProjectionFrameDevice(pairs, ck.data_ptr(), cd.data_ptr(), cn.data_ptr(), cap,
+                                             (0.0, 0.0, float(W), float(H)), q.data_ptr(), last_d.data_ptr(),
+                                             last_n.data_ptr(), cap, t_assign.data_ptr(), t_nm.data_ptr())
+            for st in streams:
+                st.wait_stream(cur)
+            return q, ck, cd, cn, last_d, last_n      # keep the operands alive until the stream has consumed them
+
+        keep_alive = [match_step() for _ in range(3)]
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            keep_alive.append(match_step())
+            if len(keep_alive) > 4:
+                keep_alive.pop(0)
+        torch.cuda.synchronize(dev)
+        dtm = time.perf_counter() - t0
+        match_info = {"value": round(B * args.steps / dtm, 1), "unit": "frames/s",
+                      "what": "extract (64 frames) + device-resident SearchByProjection(CurrentFrame, LastFrame, th=15) "
+                              "for the 32 (2k, 2k+1) pairs of each step; queries built on the GPU",
+                      "ms_per_step": round(dtm / args.steps * 1e3, 4),
+                      "mean_matches_per_pair": round(float(t_nm.float().mean().item()), 1)}
+
     if rank == 0:
         total_frames = B * world * args.steps
         fps = total_frames / dt
@@ -231,6 +288,7 @@ def main():
                          "stage_us": {k: round(v, 2) for k, v in stage.items()},
                          "whole_path_GBps_model": round(FRAME_BYTES_MODEL * fps / world / 1e9, 2)},
         }
+        out["extract_match"] = match_info
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames[:16])
         else:
