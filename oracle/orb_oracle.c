@@ -355,8 +355,10 @@ int oracle_distribute_octree(const float *x, const float *y, const float *resp, 
                              int maxX, int minY, int maxY, int N, int *out_idx, int out_cap)
 {
     /* :543 round(), :545 */
-    const int nIni = (int)roundf((float)(maxX - minX) / (maxY - minY));
-    if (nIni < 1 || n == 0) return 0; /* reference: empty list -> empty result (n==0); nIni<1 is UB there */
+    int nIni = (int)roundf((float)(maxX - minX) / (maxY - minY));
+    if (n == 0) return 0;   /* reference: empty list -> empty result */
+    if (nIni < 1) nIni = 1; /* portrait levels (w < h/2): the reference divides by zero and indexes an empty
+                               vector (:545,:569); the documented choice is a single root node */
     const float hX = (float)(maxX - minX) / nIni;
     olist L; memset(&L, 0, sizeof(L)); L.head = L.tail = -1;
     int *ini = (int *)malloc(sizeof(int) * nIni);

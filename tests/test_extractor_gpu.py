@@ -203,3 +203,46 @@ def test_full_size_batch_properties(mods):
         ok, od = ora.extract(frames[b])
         assert_kps_equal(outs[0][0][b, :n[b]].copy().view(pkg.KP_DTYPE).reshape(-1), ok)
         assert np.array_equal(outs[0][1][b, :n[b]], od)
+
+
+def _content(kind, W, H, rng):
+    if kind == "noise":
+        return rng.integers(0, 256, (H, W), dtype=np.uint8)
+    if kind == "lownoise":
+        return (rng.integers(100, 140, (H, W))).astype(np.uint8)
+    if kind == "checker":
+        s = int(rng.integers(3, 17))
+        yy, xx = np.mgrid[0:H, 0:W]
+        return (((yy // s + xx // s) % 2) * int(rng.integers(30, 200)) + 20).astype(np.uint8)
+    if kind == "gradient":
+        yy, xx = np.mgrid[0:H, 0:W]
+        return ((xx * 255 // max(W - 1, 1) + yy * 3) % 256).astype(np.uint8)
+    if kind == "blobs":
+        img = np.full((H, W), 60, np.int32)
+        for _ in range(300):
+            x, y, r = int(rng.integers(0, W)), int(rng.integers(0, H)), int(rng.integers(2, 9))
+            img[max(0, y - r):y + r, max(0, x - r):x + r] = int(rng.integers(0, 256))
+        return img.astype(np.uint8)
+    return synth_frame(int(rng.integers(1, 1000)), W, H)
+
+
+@pytest.mark.parametrize("case", range(14))
+def test_randomised_sizes_and_contents(mods, case):
+    """Random geometry (every cell alignment / partial cell / odd pitch) x content classes that stress
+    individual stages: dense corners (checker/noise: full candidate pressure, plateaus), threshold fallback
+    (low noise), no corners (gradient), sparse blobs (fewer candidates than the quota)."""
+    pkg, O = mods
+    rng = np.random.default_rng(1000 + case)
+    W, H = int(rng.integers(170, 900)), int(rng.integers(170, 700))
+    kind = ["noise", "lownoise", "checker", "gradient", "blobs", "synth", "checker"][case % 7]
+    nlevels = int(rng.integers(2, 6))           # small images: keep every level >= 40 px
+    nf = int(rng.integers(50, 1500))
+    ini, mn = int(rng.integers(10, 40)), int(rng.integers(3, 10))
+    img = _content(kind, W, H, rng)
+    ext = pkg.ORBextractor(nf, 1.2, nlevels, ini, mn)
+    ora = O.OracleExtractor(nf, 1.2, nlevels, ini, mn)
+    k, d = ext(img)
+    ok, od = ora.extract(img)
+    assert_stagewise_equal(ext, ora, nlevels, "%s %dx%d" % (kind, W, H))
+    assert_kps_equal(k, ok, "%s %dx%d" % (kind, W, H))
+    assert np.array_equal(d, od)

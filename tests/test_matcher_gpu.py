@@ -277,3 +277,16 @@ def test_device_batched_search_by_projection_equals_host_api(env):
             hn, hassign = host(view, q[p, :nq[p]], qd[p, :nq[p]], taken[p, :n1])
             assert hn == nm[p] and np.array_equal(hassign, assign[p, :n1]), (mode, p)
             assert hn > 100
+
+
+def test_matcher_capacity_limit_is_an_error_not_garbage(env):
+    """More than 4096 keypoints per frame exceeds the LDS-resident resolve state: explicit E_CAPACITY."""
+    pkg, M, O = env
+    n = 4100
+    k = np.zeros(n, pkg.KP_DTYPE); k["x"] = np.arange(n) % 600 + 20; k["y"] = np.arange(n) // 600 * 5 + 20
+    d = np.random.default_rng(0).integers(0, 256, (n, 32), dtype=np.uint8)
+    fv = pkg.FrameView(k, d, np.ones(8, np.float32), (0, 0, 640, 480))
+    q = np.zeros(10, pkg.QUERY_DTYPE); q["valid"] = 1; q["u"] = 100; q["v"] = 50; q["radius"] = 10; q["min_level"] = -1; q["max_level"] = -1
+    with pytest.raises(pkg.OrbHipError) as ei:
+        pkg.ORBmatcher().SearchByProjectionFrame(fv, q, d[:10])
+    assert ei.value.code == -3
