@@ -19,6 +19,10 @@
  *   orbhip_search_by_projection_points ORBmatcher::SearchByProjection(Frame&,vector<MapPoint*>&,th)
  *                                     (src/ORBmatcher.cc:45-129)
  *   orbhip_compute_stereo_matches     Frame::ComputeStereoMatches (src/Frame.cc:466-640)
+ *   orbhip_search_by_projection_keyframe ORBmatcher::SearchByProjection(Frame&,KeyFrame*,sAlreadyFound,th,ORBdist)
+ *                                     (src/ORBmatcher.cc:1472-1599, relocalisation)
+ *   orbhip_search_by_projection_sim3  ORBmatcher::SearchByProjection(KeyFrame*,Scw,vpPoints,vpMatched,th)
+ *                                     (src/ORBmatcher.cc:290-403, loop closing)
  */
 #ifndef ORBHIP_H
 #define ORBHIP_H
@@ -173,6 +177,22 @@ int orbhip_search_by_projection_points(orbhip_matcher *m, const orbhip_frame_vie
                                        const orbhip_query *q, const uint8_t *qdesc, int nq,
                                        const uint8_t *taken, int32_t *assign, float nnratio,
                                        int *nmatches);
+
+/* ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) after projection
+ * (src/ORBmatcher.cc:1490-1527 stay in the caller: valid = map point exists, !isBad(), not in sAlreadyFound, projects
+ * inside the image and inside its scale-invariance range; radius = th*scale[predicted]; levels [pred-1, pred+1]).
+ * taken[n]: CurrentFrame.mvpMapPoints[i2] != NULL on entry.  Every accepted match blocks its slot (:1538-1539);
+ * accept iff best distance <= orb_dist (:1552); rotation histogram as in the frame-to-frame search. */
+int orbhip_search_by_projection_keyframe(orbhip_matcher *m, const orbhip_frame_view *cur, const orbhip_query *q,
+                                         const uint8_t *qdesc, int nq, const uint8_t *taken, int32_t *assign,
+                                         int orb_dist, int check_ori, int *nmatches);
+
+/* ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) after the Sim3 projection (:315-359 stay in the
+ * caller; radius = th*scale[pred], levels [pred-1, pred]).  kf: the KeyFrame's keypoints/descriptors/grid;
+ * matched[n]: vpMatched[idx] != NULL on entry; accept iff best distance <= TH_LOW (:393); no orientation check. */
+int orbhip_search_by_projection_sim3(orbhip_matcher *m, const orbhip_frame_view *kf, const orbhip_query *q,
+                                     const uint8_t *qdesc, int nq, const uint8_t *matched, int32_t *assign,
+                                     int *nmatches);
 
 /* Device-resident, batched forms of the two SearchByProjection searches: `pairs` independent frame pairs,
  * asynchronous on the matcher's stream.  Train side in the extractor's output layout: d_kps [pairs][cap]

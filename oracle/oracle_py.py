@@ -84,6 +84,8 @@ def lib():
                                                        C.c_float, C.c_int]
         L.oracle_search_by_projection_frame.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p,
                                                         C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_search_by_projection_block.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                        C.c_void_p, C.c_int, C.c_int]
         L.oracle_search_by_projection_points.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p,
                                                          C.c_int, C.c_void_p, C.c_void_p, C.c_float]
         L.oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
@@ -224,6 +226,16 @@ def search_by_projection_frame(cur, queries, qdesc, taken=None, check_ori=True):
     out = np.zeros(max(cur.n, 1), np.int32)
     n = lib().oracle_search_by_projection_frame(C.byref(cur), _p(q), _p(qd), len(q), _p(tk),
                                                 _p(out), int(check_ori))
+    return n, out[:cur.n].copy()
+
+
+def search_by_projection_block(cur, queries, qdesc, taken=None, max_dist=100, check_ori=True):
+    q = np.ascontiguousarray(queries, QUERY_DTYPE)
+    qd = np.ascontiguousarray(qdesc, np.uint8)
+    tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+    out = np.zeros(max(cur.n, 1), np.int32)
+    n = lib().oracle_search_by_projection_block(C.byref(cur), _p(q), _p(qd), len(q), _p(tk), _p(out), max_dist,
+                                                int(check_ori))
     return n, out[:cur.n].copy()
 
 

@@ -927,6 +927,52 @@ int oracle_search_by_projection_frame(const oracle_frame *cur, const oracle_quer
     return nmatches;
 }
 
+/* SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), ORBmatcher.cc:1472-1599 after the projection
+ * (:1490-1527 arrive in q[]); with max_dist = TH_LOW and check_ori = 0 it is also the matching loop of
+ * SearchByProjection(pKF, Scw, vpPoints, vpMatched, th), :361-398 (same grid query, every match blocks its slot). */
+int oracle_search_by_projection_block(const oracle_frame *cur, const oracle_query *q, const uint8_t *qdesc, int nq,
+                                      const uint8_t *taken_in, int32_t *assign, int max_dist, int check_ori)
+{
+    int nmatches = 0;
+    const int n = cur->n;
+    uint8_t *taken = (uint8_t *)malloc(n + 1);
+    int32_t *ind = (int32_t *)malloc(sizeof(int32_t) * (n + 1));
+    int *hist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (nq + 1));
+    int hs[HISTO_LENGTH] = {0};
+    for (int i = 0; i < n; ++i) { taken[i] = taken_in ? taken_in[i] : 0; assign[i] = -1; }
+    for (int i = 0; i < nq; ++i) {
+        if (!q[i].valid) continue;
+        int nind = oracle_features_in_area(cur, q[i].u, q[i].v, q[i].radius, q[i].min_level, q[i].max_level, ind, n);
+        if (nind == 0) continue;
+        const uint8_t *dMP = qdesc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nind; ++c) {
+            const int i2 = ind[c];
+            if (taken[i2]) continue;                       /* :1538-1539 / :371-372 */
+            const int dist = oracle_descriptor_distance(dMP, cur->desc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= max_dist) {                        /* :1552 / :393 */
+            assign[bestIdx2] = i;
+            taken[bestIdx2] = 1;
+            nmatches++;
+            if (check_ori) {
+                int bin = rot_bin(q[i].angle, cur->keys[bestIdx2].angle);
+                hist[bin * nq + hs[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_ori) {
+        int ind1, ind2, ind3;
+        oracle_three_maxima(hs, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < hs[i]; ++j) { assign[hist[i * nq + j]] = -1; nmatches--; }
+    }
+    free(taken); free(ind); free(hist);
+    return nmatches;
+}
+
 /* SearchByProjection(Frame&,const vector<MapPoint*>&,th), ORBmatcher.cc:45-129 */
 int oracle_search_by_projection_points(const oracle_frame *f, const oracle_query *q,
                                        const uint8_t *qdesc, int nq, const uint8_t *taken_in,

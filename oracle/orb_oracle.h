@@ -135,6 +135,11 @@ int oracle_search_by_projection_frame(const oracle_frame *cur, const oracle_quer
                                       const uint8_t *qdesc, int nq, const uint8_t *taken,
                                       int32_t *out_assign, int check_ori);
 
+/* ORBmatcher::SearchByProjection(Frame&,KeyFrame*,sAlreadyFound,th,ORBdist) :1472-1599 and the matching loop
+ * of SearchByProjection(KeyFrame*,Scw,vpPoints,vpMatched,th) :361-398 (max_dist = TH_LOW, check_ori = 0) */
+int oracle_search_by_projection_block(const oracle_frame *cur, const oracle_query *q, const uint8_t *qdesc, int nq,
+                                      const uint8_t *taken, int32_t *out_assign, int max_dist, int check_ori);
+
 /* ORBmatcher::SearchByProjection(Frame&,vector<MapPoint*>,th) :45-129 */
 int oracle_search_by_projection_points(const oracle_frame *f, const oracle_query *q,
                                        const uint8_t *qdesc, int nq, const uint8_t *taken,

@@ -406,7 +406,8 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                                                       const unsigned long long *__restrict__ cand,
                                                       const int *__restrict__ cnt, int stride,
                                                       const uint8_t *__restrict__ taken_in, float nnratio,
-                                                      int check_ori, int *__restrict__ out, int *__restrict__ out_n, Batch B)
+                                                      int check_ori, int *__restrict__ out, int *__restrict__ out_n, Batch B,
+                                                      int th_accept, int all_block)
 {
     extern __shared__ unsigned char resolve_lds[];
     ResolveParShared &S = *reinterpret_cast<ResolveParShared *>(resolve_lds);
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     for (int i = tid; i < nq; i += T) {
         S.choice[i] = -2;   // "not evaluated yet"
         S.q_angle[i] = q[i].angle;
-        S.q_obs[i] = (unsigned char)(q[i].observed != 0);
+        S.q_obs[i] = (unsigned char)(all_block || q[i].observed != 0);
         S.evbin[i] = 0xff;
     }
     if (tid < HISTO_LENGTH) S.hist[tid] = 0;
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                 }
                 if (k1 != ~0ull) {
                     const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xfffffu);
-                    bool acc = bestDist <= TH_HIGH;
+                    bool acc = bestDist <= th_accept;
                     if (acc && mode == 1) {
                         const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
                         const int bestLevel = S.t_oct[bestIdx];
@@ -814,7 +815,8 @@ static int ensure_resolve_attr(orbhip_matcher *m)
 // shared driver of the three windowed searches
 static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *train, const orbhip_query *q,
                       const uint8_t *qdesc, const orbhip_keypoint *qkeys, int nq, const uint8_t *taken,
-                      float nnratio, int check_ori, int32_t *out, int nout, int *nmatches)
+                      float nnratio, int check_ori, int32_t *out, int nout, int *nmatches, int th_accept = TH_HIGH,
+                      int all_block = 0, int use_ur = 1)
 {
     ORBHIP_HIP_CHECK(hipSetDevice(m->device));
     if (train->n > kResolveMax || nq > kResolveMax) {
@@ -855,14 +857,14 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
     const Batch one = {nullptr, nullptr, 0, 0};
     hipLaunchKernelGGL(k_grid_order, dim3((train->n + 255) / 256), dim3(256), 0, m->stream, D, d_ord, one);
     hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_ord, d_q, d_qdesc, nq, d_cand,
-                       d_cnt, stride, mode != 2, one);
+                       d_cnt, stride, mode != 2 && use_ur, one);
     if ((rc = ensure_resolve_attr(m))) return rc;
     if (mode == 2)   // SearchForInitialization: match stealing depends on the running minimum distance -> serial replay
         hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(ResolveShared), m->stream, mode, D, d_qkeys, d_q, nq, d_cand,
                            d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout);
     else
         hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), sizeof(ResolveParShared), m->stream, mode, D, d_q, nq, d_cand,
-                           d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout, one);
+                           d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout, one, th_accept, all_block);
     ORBHIP_HIP_CHECK(hipGetLastError());
     ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)(nout + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -962,6 +964,21 @@ int orbhip_search_by_projection_frame(orbhip_matcher *m, const orbhip_frame_view
     return run_search(m, 0, cur, q, qdesc, nullptr, nq, taken, 0.f, check_ori, assign, cur->n, nmatches);
 }
 
+int orbhip_search_by_projection_keyframe(orbhip_matcher *m, const orbhip_frame_view *cur, const orbhip_query *q,
+                                         const uint8_t *qdesc, int nq, const uint8_t *taken, int32_t *assign,
+                                         int orb_dist, int check_ori, int *nmatches)
+{
+    if (!m || !cur || (nq > 0 && (!q || !qdesc)) || !assign || !nmatches || nq < 0) return ORBHIP_E_ARG;
+    return run_search(m, 0, cur, q, qdesc, nullptr, nq, taken, 0.f, check_ori, assign, cur->n, nmatches, orb_dist, 1, 0);
+}
+
+int orbhip_search_by_projection_sim3(orbhip_matcher *m, const orbhip_frame_view *kf, const orbhip_query *q,
+                                     const uint8_t *qdesc, int nq, const uint8_t *matched, int32_t *assign, int *nmatches)
+{
+    if (!m || !kf || (nq > 0 && (!q || !qdesc)) || !assign || !nmatches || nq < 0) return ORBHIP_E_ARG;
+    return run_search(m, 0, kf, q, qdesc, nullptr, nq, matched, 0.f, 0, assign, kf->n, nmatches, TH_LOW, 1, 0);
+}
+
 int orbhip_search_by_projection_points(orbhip_matcher *m, const orbhip_frame_view *f, const orbhip_query *q,
                                        const uint8_t *qdesc, int nq, const uint8_t *taken, int32_t *assign,
                                        float nnratio, int *nmatches)
@@ -1001,7 +1018,7 @@ static int search_device(orbhip_matcher *m, int mode, int pairs, const void *d_k
                        (const uint8_t *)d_qdesc, qcap, d_cand, d_cnt, stride, 1, B);
     hipLaunchKernelGGL(k_resolve_par, dim3(pairs), dim3(1024), sizeof(ResolveParShared), m->stream, mode, D,
                        (const orbhip_query *)d_q, qcap, d_cand, d_cnt, stride, (const uint8_t *)d_taken, nnratio, check_ori,
-                       (int *)d_assign, (int *)d_nmatches, B);
+                       (int *)d_assign, (int *)d_nmatches, B, TH_HIGH, 0);
     ORBHIP_HIP_CHECK(hipGetLastError());
     return ORBHIP_OK;
 }

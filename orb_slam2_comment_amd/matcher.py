@@ -115,6 +115,31 @@ class ORBmatcher:
               "orbhip_search_by_projection_points")
         return n.value, out[:F.N].copy()
 
+    # -- SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:1472-1599) ---
+    def SearchByProjectionKeyFrame(self, CurrentFrame, queries, query_desc, taken=None, ORBdist=100):
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        qd = np.ascontiguousarray(query_desc, np.uint8).reshape(-1, 32)
+        tk = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+        out = np.full(max(CurrentFrame.N, 1), -1, np.int32)
+        n = C.c_int()
+        v = CurrentFrame.c_view()
+        check(self._lib.orbhip_search_by_projection_keyframe(self._h, C.byref(v), ptr(q), ptr(qd), len(q), ptr(tk),
+                                                             ptr(out), int(ORBdist), int(self.mbCheckOrientation),
+                                                             C.byref(n)), "orbhip_search_by_projection_keyframe")
+        return n.value, out[:CurrentFrame.N].copy()
+
+    # -- SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (:290-403) -------
+    def SearchByProjectionSim3(self, KF, queries, query_desc, matched=None):
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        qd = np.ascontiguousarray(query_desc, np.uint8).reshape(-1, 32)
+        tk = None if matched is None else np.ascontiguousarray(matched, np.uint8)
+        out = np.full(max(KF.N, 1), -1, np.int32)
+        n = C.c_int()
+        v = KF.c_view()
+        check(self._lib.orbhip_search_by_projection_sim3(self._h, C.byref(v), ptr(q), ptr(qd), len(q), ptr(tk), ptr(out),
+                                                         C.byref(n)), "orbhip_search_by_projection_sim3")
+        return n.value, out[:KF.N].copy()
+
     # -- device-resident, batched SearchByProjection ---------------------------
     def set_stream(self, stream):
         check(self._lib.orbhip_matcher_set_stream(self._h, stream), "orbhip_matcher_set_stream")

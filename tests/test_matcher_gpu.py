@@ -290,3 +290,36 @@ def test_matcher_capacity_limit_is_an_error_not_garbage(env):
     with pytest.raises(pkg.OrbHipError) as ei:
         pkg.ORBmatcher().SearchByProjectionFrame(fv, q, d[:10])
     assert ei.value.code == -3
+
+
+@pytest.mark.parametrize("th,orb_dist,ori", [(10, 100, True), (3, 64, True), (10, 100, False)])
+def test_search_by_projection_keyframe_and_sim3(env, th, orb_dist, ori):
+    """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (src/Tracking.cc:1452,1466: th 10/3,
+    ORBdist 100/64) and SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (src/LoopClosing.cc:239,589)."""
+    pkg, M, O = env
+    rng = np.random.default_rng(th * 1000 + orb_dist + ori)
+    ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    img_kf, img_cur = synth_frame(8), synth_frame(8, shift_xy=(2, 1))
+    k_kf, d_kf = ext(img_kf)
+    k_cur, d_cur = ext(img_cur)
+    sf = ext.GetScaleFactors()
+    gv, ov, keep = _views(pkg, O, img_cur, k_cur, d_cur, sf)
+    nq = len(k_kf)
+    q = np.zeros(nq, pkg.QUERY_DTYPE)
+    q["valid"] = rng.random(nq) < 0.9
+    q["u"] = k_kf["x"] + 2 + rng.normal(0, 1.5, nq).astype(np.float32)
+    q["v"] = k_kf["y"] + 1 + rng.normal(0, 1.5, nq).astype(np.float32)
+    pred = np.clip(k_kf["octave"] + rng.integers(-1, 2, nq), 0, 7)
+    q["radius"] = np.float32(th) * sf[pred]
+    q["min_level"], q["max_level"] = pred - 1, pred + 1
+    q["angle"] = k_kf["angle"]
+    taken = (rng.random(len(k_cur)) < 0.15).astype(np.uint8)
+    m = pkg.ORBmatcher(0.9, ori)
+    n, a = m.SearchByProjectionKeyFrame(gv, q, d_kf, taken, ORBdist=orb_dist)
+    on, oa = O.search_by_projection_block(ov, q, d_kf, taken, orb_dist, ori)
+    assert n == on and np.array_equal(a, oa) and n > 50
+    # loop-closing variant: levels [pred-1, pred], TH_LOW, no orientation check
+    q["min_level"], q["max_level"] = pred - 1, pred
+    n, a = m.SearchByProjectionSim3(gv, q, d_kf, taken)
+    on, oa = O.search_by_projection_block(ov, q, d_kf, taken, 50, False)
+    assert n == on and np.array_equal(a, oa) and n > 50
