@@ -23,6 +23,8 @@
  *                                     (src/ORBmatcher.cc:1472-1599, relocalisation)
  *   orbhip_search_by_projection_sim3  ORBmatcher::SearchByProjection(KeyFrame*,Scw,vpPoints,vpMatched,th)
  *                                     (src/ORBmatcher.cc:290-403, loop closing)
+ *   orbhip_search_best_in_window      inner search of ORBmatcher::Fuse x2 (src/ORBmatcher.cc:825-1100) and of both
+ *                                     directions of SearchBySim3 (:1102-1326)
  */
 #ifndef ORBHIP_H
 #define ORBHIP_H
@@ -193,6 +195,16 @@ int orbhip_search_by_projection_keyframe(orbhip_matcher *m, const orbhip_frame_v
 int orbhip_search_by_projection_sim3(orbhip_matcher *m, const orbhip_frame_view *kf, const orbhip_query *q,
                                      const uint8_t *qdesc, int nq, const uint8_t *matched, int32_t *assign,
                                      int *nmatches);
+
+/* Independent best match per query (no slot blocking): the search loop of ORBmatcher::Fuse(pKF, vpMapPoints, th)
+ * (src/ORBmatcher.cc:893-950), Fuse(pKF, Scw, ...) (:1045-1075) and of both directions of SearchBySim3 (:1199-1219,
+ * :1279-1299).  Candidates = KeyFrame::GetFeaturesInArea(u, v, radius) with octave in [min_level, max_level]
+ * (= [pred-1, pred]); chi2_gate != 0 adds Fuse's reprojection gate (e2*mvInvLevelSigma2[level] > 5.99 mono / 7.8
+ * when mvuRight[idx] >= 0, using q.ur).  best_idx[nq] (-1 if no candidate), best_dist[nq] (256 if none): the caller
+ * applies its threshold (TH_LOW / TH_HIGH) and the map-graph side effects in order. */
+int orbhip_search_best_in_window(orbhip_matcher *m, const orbhip_frame_view *kf, const orbhip_query *q,
+                                 const uint8_t *qdesc, int nq, int chi2_gate, const float *inv_level_sigma2,
+                                 int32_t *best_idx, int32_t *best_dist);
 
 /* Device-resident, batched forms of the two SearchByProjection searches: `pairs` independent frame pairs,
  * asynchronous on the matcher's stream.  Train side in the extractor's output layout: d_kps [pairs][cap]

@@ -86,6 +86,8 @@ def lib():
                                                         C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_search_by_projection_block.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                         C.c_void_p, C.c_int, C.c_int]
+        L.oracle_search_best_in_window.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p]
         L.oracle_search_by_projection_points.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p,
                                                          C.c_int, C.c_void_p, C.c_void_p, C.c_float]
         L.oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
@@ -237,6 +239,16 @@ def search_by_projection_block(cur, queries, qdesc, taken=None, max_dist=100, ch
     n = lib().oracle_search_by_projection_block(C.byref(cur), _p(q), _p(qd), len(q), _p(tk), _p(out), max_dist,
                                                 int(check_ori))
     return n, out[:cur.n].copy()
+
+
+def search_best_in_window(kf, queries, qdesc, inv_sigma2=None):
+    q = np.ascontiguousarray(queries, QUERY_DTYPE)
+    qd = np.ascontiguousarray(qdesc, np.uint8)
+    sig = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+    bi = np.zeros(max(len(q), 1), np.int32)
+    bd = np.zeros(max(len(q), 1), np.int32)
+    lib().oracle_search_best_in_window(C.byref(kf), _p(q), _p(qd), len(q), _p(sig), _p(bi), _p(bd))
+    return bi[:len(q)].copy(), bd[:len(q)].copy()
 
 
 def search_by_projection_points(f, queries, qdesc, taken=None, nnratio=0.8):

@@ -973,6 +973,43 @@ int oracle_search_by_projection_block(const oracle_frame *cur, const oracle_quer
     return nmatches;
 }
 
+/* Search loop of Fuse (ORBmatcher.cc:893-950; the Sim3 overload :1045-1075 has no chi2 gate) and of SearchBySim3
+ * (:1199-1219, :1279-1299): best candidate per query, no blocking.  inv_sigma2 == NULL disables the chi2 gate. */
+void oracle_search_best_in_window(const oracle_frame *kf, const oracle_query *q, const uint8_t *qdesc, int nq,
+                                  const float *inv_sigma2, int32_t *best_idx, int32_t *best_dist)
+{
+    const int n = kf->n;
+    int32_t *ind = (int32_t *)malloc(sizeof(int32_t) * (n + 1));
+    for (int i = 0; i < nq; ++i) {
+        best_idx[i] = -1; best_dist[i] = 256;
+        if (!q[i].valid) continue;
+        const float u = q[i].u, v = q[i].v, ur = q[i].ur;
+        int nind = oracle_features_in_area(kf, u, v, q[i].radius, -1, -1, ind, n);  /* KeyFrame::GetFeaturesInArea */
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nind; ++c) {
+            const int idx = ind[c];
+            const oracle_kp *kp = &kf->keys[idx];
+            const int kpLevel = kp->octave;
+            if (kpLevel < q[i].min_level || kpLevel > q[i].max_level) continue;
+            if (inv_sigma2) {
+                if (kf->u_right && kf->u_right[idx] >= 0) {
+                    const float ex = u - kp->x, ey = v - kp->y, er = ur - kf->u_right[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = u - kp->x, ey = v - kp->y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = oracle_descriptor_distance(qdesc + (size_t)i * 32, kf->desc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist;
+    }
+    free(ind);
+}
+
 /* SearchByProjection(Frame&,const vector<MapPoint*>&,th), ORBmatcher.cc:45-129 */
 int oracle_search_by_projection_points(const oracle_frame *f, const oracle_query *q,
                                        const uint8_t *qdesc, int nq, const uint8_t *taken_in,

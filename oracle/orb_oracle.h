@@ -140,6 +140,10 @@ int oracle_search_by_projection_frame(const oracle_frame *cur, const oracle_quer
 int oracle_search_by_projection_block(const oracle_frame *cur, const oracle_query *q, const uint8_t *qdesc, int nq,
                                       const uint8_t *taken, int32_t *out_assign, int max_dist, int check_ori);
 
+/* search loop of ORBmatcher::Fuse (:893-950, :1045-1075) and SearchBySim3 (:1199-1219, :1279-1299) */
+void oracle_search_best_in_window(const oracle_frame *kf, const oracle_query *q, const uint8_t *qdesc, int nq,
+                                  const float *inv_sigma2, int32_t *best_idx, int32_t *best_dist);
+
 /* ORBmatcher::SearchByProjection(Frame&,vector<MapPoint*>,th) :45-129 */
 int oracle_search_by_projection_points(const oracle_frame *f, const oracle_query *q,
                                        const uint8_t *qdesc, int nq, const uint8_t *taken,

@@ -66,6 +66,7 @@ SYMBOLS = [
                                                 _f, _pi]),
     ("orbhip_search_by_projection_keyframe", _i, [_vp, C.POINTER(FrameView), _vp, _vp, _i, _vp, _vp, _i, _i, _pi]),
     ("orbhip_search_by_projection_sim3", _i, [_vp, C.POINTER(FrameView), _vp, _vp, _i, _vp, _vp, _pi]),
+    ("orbhip_search_best_in_window", _i, [_vp, C.POINTER(FrameView), _vp, _vp, _i, _i, _vp, _vp, _vp]),
     ("orbhip_search_by_projection_frame_device", _i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp,
                                                       _vp, _i, _i, _vp, _vp]),
     ("orbhip_search_by_projection_points_device", _i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp,

@@ -184,6 +184,73 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const uint32_
     }
 }
 
+// ---- independent best match per query (no slot blocking) ------------------------------------
+// Inner loop of ORBmatcher::Fuse (ORBmatcher.cc:893-950, :1045-1075) and of both directions of SearchBySim3
+// (:1199-1219, :1279-1299): GetFeaturesInArea window, level window, optional chi-square gate on the
+// reprojection error (Fuse: 5.99 mono / 7.8 stereo, scaled by mvInvLevelSigma2[level]), Hamming argmin with the
+// reference's first-minimum tie-break.  One wavefront per query.
+struct SigmaTab { float inv_sigma2[ORBHIP_MAX_LEVELS]; };
+
+__global__ __launch_bounds__(256) void k_best_in_window(DevFrame F, const uint32_t *__restrict__ ord,
+                                                        const orbhip_query *__restrict__ q,
+                                                        const uint8_t *__restrict__ qdesc, int nq, int chi2_gate,
+                                                        SigmaTab sig, int *__restrict__ best_idx,
+                                                        int *__restrict__ best_dist)
+{
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const orbhip_query Q = q[qi];
+    unsigned long long best = ~0ull;
+    if (Q.valid) {
+        const float x = Q.u, y = Q.v, r = Q.radius;
+        const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, F.min_x), r), F.inv_w)));
+        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, F.min_x), r), F.inv_w)));
+        const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, F.min_y), r), F.inv_h)));
+        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, F.min_y), r), F.inv_h)));
+        if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+            uint32_t qd[8];
+            const uint32_t *qp = reinterpret_cast<const uint32_t *>(qdesc + (size_t)qi * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qd[i] = qp[i];
+            for (int j0 = 0; j0 < F.n; j0 += 64) {
+                const int j = j0 + lane;
+                if (j >= F.n) continue;
+                const uint32_t o = ord[j];
+                if (o == kNoCell) continue;
+                const int cell = (int)(o >> 20);
+                const int px = cell / GRID_ROWS, py = cell - px * GRID_ROWS;
+                if (!(px >= nMinCellX && px <= nMaxCellX && py >= nMinCellY && py <= nMaxCellY)) continue;
+                const orbhip_keypoint kp = F.keys[j];
+                if (!(fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r)) continue;
+                if (kp.octave < Q.min_level || kp.octave > Q.max_level) continue;   // kpLevel<pred-1 || kpLevel>pred
+                if (chi2_gate) {
+                    const float ex = __fsub_rn(x, kp.x), ey = __fsub_rn(y, kp.y);
+                    float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                    const float kpr = F.u_right ? F.u_right[j] : -1.0f;
+                    const float is2 = sig.inv_sigma2[kp.octave];
+                    if (kpr >= 0) {
+                        const float er = __fsub_rn(Q.ur, kpr);
+                        e2 = __fadd_rn(e2, __fmul_rn(er, er));
+                        if ((double)__fmul_rn(e2, is2) > 7.8) continue;
+                    } else if ((double)__fmul_rn(e2, is2) > 5.99) continue;
+                }
+                const uint32_t *tp = reinterpret_cast<const uint32_t *>(F.desc + (size_t)j * 32);
+                uint32_t td[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) td[i] = tp[i];
+                const unsigned long long key = ((unsigned long long)hamming256(qd, td) << 32) | o;
+                best = key < best ? key : best;
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) {
+        best_idx[qi] = best == ~0ull ? -1 : (int)(best & 0xfffffu);
+        best_dist[qi] = best == ~0ull ? 256 : (int)(best >> 32);
+    }
+}
+
 // ---- resolve ---------------------------------------------------------------------------
 // mode 0: SearchByProjection(Frame,Frame)  ORBmatcher.cc:1397-1467
 // mode 1: SearchByProjection(Frame,points) ORBmatcher.cc:76-125
@@ -977,6 +1044,51 @@ int orbhip_search_by_projection_sim3(orbhip_matcher *m, const orbhip_frame_view 
 {
     if (!m || !kf || (nq > 0 && (!q || !qdesc)) || !assign || !nmatches || nq < 0) return ORBHIP_E_ARG;
     return run_search(m, 0, kf, q, qdesc, nullptr, nq, matched, 0.f, 0, assign, kf->n, nmatches, TH_LOW, 1, 0);
+}
+
+int orbhip_search_best_in_window(orbhip_matcher *m, const orbhip_frame_view *kf, const orbhip_query *q,
+                                 const uint8_t *qdesc, int nq, int chi2_gate, const float *inv_level_sigma2,
+                                 int32_t *best_idx, int32_t *best_dist)
+{
+    if (!m || !kf || nq < 0 || (nq > 0 && (!q || !qdesc || !best_idx || !best_dist)) || (chi2_gate && !inv_level_sigma2))
+        return ORBHIP_E_ARG;
+    for (int i = 0; i < nq; ++i) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (nq == 0 || kf->n == 0) return ORBHIP_OK;
+    if (kf->n >= (1 << 20)) { set_error("too many keypoints"); return ORBHIP_E_CAPACITY; }
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    const size_t n = (size_t)kf->n;
+    Stage st;
+    int rc;
+    if ((rc = stage_begin(m, al256(n * sizeof(orbhip_keypoint)) + al256(n * 32) + al256(n * 4) +
+                                 al256((size_t)nq * sizeof(orbhip_query)) + al256((size_t)nq * 32), &st))) return rc;
+    DevFrame D;
+    D.n = kf->n; D.min_x = kf->min_x; D.min_y = kf->min_y; D.inv_w = kf->grid_inv_w; D.inv_h = kf->grid_inv_h;
+    D.keys = (const orbhip_keypoint *)st.put(kf->keys, n * sizeof(orbhip_keypoint));
+    D.desc = (const uint8_t *)st.put(kf->desc, n * 32);
+    D.u_right = kf->u_right ? (const float *)st.put(kf->u_right, n * sizeof(float)) : nullptr;
+    const orbhip_query *d_q = (const orbhip_query *)st.put(q, (size_t)nq * sizeof(orbhip_query));
+    const uint8_t *d_qdesc = (const uint8_t *)st.put(qdesc, (size_t)nq * 32);
+    if ((rc = stage_commit(m, &st))) return rc;
+    void *p;
+    if ((rc = scratch(m, S_ORD, n * sizeof(uint32_t), &p))) return rc;
+    uint32_t *d_ord = (uint32_t *)p;
+    if ((rc = scratch(m, S_OUT, (size_t)nq * 2 * sizeof(int), &p))) return rc;
+    int *d_out = (int *)p;
+    uint8_t *h_out;
+    if ((rc = out_buffer(m, (size_t)nq * 2 * sizeof(int), &h_out))) return rc;
+    SigmaTab sig;
+    memset(&sig, 0, sizeof(sig));
+    if (inv_level_sigma2) for (int l = 0; l < std::min(kf->n_levels, ORBHIP_MAX_LEVELS); ++l) sig.inv_sigma2[l] = inv_level_sigma2[l];
+    const Batch one = {nullptr, nullptr, 0, 0};
+    hipLaunchKernelGGL(k_grid_order, dim3((kf->n + 255) / 256), dim3(256), 0, m->stream, D, d_ord, one);
+    hipLaunchKernelGGL(k_best_in_window, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_ord, d_q, d_qdesc, nq, chi2_gate,
+                       sig, d_out, d_out + nq);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    memcpy(best_idx, h_out, (size_t)nq * sizeof(int));
+    memcpy(best_dist, h_out + (size_t)nq * sizeof(int), (size_t)nq * sizeof(int));
+    return ORBHIP_OK;
 }
 
 int orbhip_search_by_projection_points(orbhip_matcher *m, const orbhip_frame_view *f, const orbhip_query *q,

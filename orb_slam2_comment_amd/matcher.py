@@ -140,6 +140,20 @@ class ORBmatcher:
                                                          C.byref(n)), "orbhip_search_by_projection_sim3")
         return n.value, out[:KF.N].copy()
 
+    # -- inner search of Fuse x2 (:825-1100) and SearchBySim3 (:1102-1326) -------
+    def SearchBestInWindow(self, KF, queries, query_desc, inv_level_sigma2=None):
+        """Independent best match per query; chi-square gate enabled when inv_level_sigma2 is given (Fuse).
+        Returns (best_idx[nq], best_dist[nq])."""
+        q = np.ascontiguousarray(queries, QUERY_DTYPE)
+        qd = np.ascontiguousarray(query_desc, np.uint8).reshape(-1, 32)
+        bi = np.full(max(len(q), 1), -1, np.int32)
+        bd = np.full(max(len(q), 1), 256, np.int32)
+        sig = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        v = KF.c_view()
+        check(self._lib.orbhip_search_best_in_window(self._h, C.byref(v), ptr(q), ptr(qd), len(q), int(sig is not None),
+                                                     ptr(sig), ptr(bi), ptr(bd)), "orbhip_search_best_in_window")
+        return bi[:len(q)].copy(), bd[:len(q)].copy()
+
     # -- device-resident, batched SearchByProjection ---------------------------
     def set_stream(self, stream):
         check(self._lib.orbhip_matcher_set_stream(self._h, stream), "orbhip_matcher_set_stream")

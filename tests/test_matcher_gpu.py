@@ -323,3 +323,33 @@ def test_search_by_projection_keyframe_and_sim3(env, th, orb_dist, ori):
     n, a = m.SearchByProjectionSim3(gv, q, d_kf, taken)
     on, oa = O.search_by_projection_block(ov, q, d_kf, taken, 50, False)
     assert n == on and np.array_equal(a, oa) and n > 50
+
+
+@pytest.mark.parametrize("th,stereo,gate", [(3.0, True, True), (3.0, False, True), (7.5, False, False), (4.0, True, False)])
+def test_search_best_in_window_fuse_and_sim3(env, th, stereo, gate):
+    """Search loop of ORBmatcher::Fuse (th 3.0 in LocalMapping, chi2 gate 5.99/7.8) and of SearchBySim3 (th 7.5,
+    no gate): independent best match per query."""
+    pkg, M, O = env
+    rng = np.random.default_rng(int(th * 10) + 2 * stereo + gate)
+    ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    img_a, img_b = synth_frame(12), synth_frame(12, shift_xy=(1, 1))
+    ka, da = ext(img_a)
+    kb, db = ext(img_b)
+    sf = ext.GetScaleFactors()
+    inv_sig2 = ext.GetInverseScaleSigmaSquares()
+    ur = np.where(rng.random(len(kb)) < 0.6, kb["x"] - rng.uniform(2, 60, len(kb)), -1).astype(np.float32) if stereo else None
+    gv, ov, keep = _views(pkg, O, img_b, kb, db, sf, ur)
+    nq = len(ka)
+    q = np.zeros(nq, pkg.QUERY_DTYPE)
+    q["valid"] = rng.random(nq) < 0.9
+    q["u"] = ka["x"] + 1 + rng.normal(0, 1.0, nq).astype(np.float32)
+    q["v"] = ka["y"] + 1 + rng.normal(0, 1.0, nq).astype(np.float32)
+    pred = np.clip(ka["octave"] + rng.integers(0, 2, nq), 0, 7)
+    q["radius"] = np.float32(th) * sf[pred]
+    q["min_level"], q["max_level"] = pred - 1, pred
+    q["ur"] = q["u"] - rng.uniform(2, 60, nq).astype(np.float32)
+    m = pkg.ORBmatcher()
+    bi, bd = m.SearchBestInWindow(gv, q, da, inv_sig2 if gate else None)
+    obi, obd = O.search_best_in_window(ov, q, da, inv_sig2 if gate else None)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    assert (bd <= 50).sum() > 50
