@@ -246,3 +246,48 @@ def test_randomised_sizes_and_contents(mods, case):
     assert_stagewise_equal(ext, ora, nlevels, "%s %dx%d" % (kind, W, H))
     assert_kps_equal(k, ok, "%s %dx%d" % (kind, W, H))
     assert np.array_equal(d, od)
+
+
+def test_two_extractors_on_two_host_threads(mods):
+    """Frame's stereo constructor runs the left and right extractor on two std::threads
+    (src/Frame.cc:78-81): handles must be independent."""
+    import threading
+    pkg, O = mods
+    from helpers import synth_stereo
+    left, right = synth_stereo(5, 752, 480)
+    eL, eR = pkg.ORBextractor(1200, 1.2, 8, 20, 7), pkg.ORBextractor(1200, 1.2, 8, 20, 7)
+    res = {}
+
+    def run(name, ext, img):
+        for _ in range(5):
+            res[name] = ext(img)
+    tl = threading.Thread(target=run, args=("L", eL, left))
+    tr = threading.Thread(target=run, args=("R", eR, right))
+    tl.start(); tr.start(); tl.join(); tr.join()
+    ora = O.OracleExtractor(1200, 1.2, 8, 20, 7)
+    for name, img in (("L", left), ("R", right)):
+        ok, od = ora.extract(img)
+        assert_kps_equal(res[name][0], ok, name)
+        assert np.array_equal(res[name][1], od)
+
+
+def test_batch_with_frame_and_row_strides(mods):
+    """orbhip_extract_batch on frames that are ROIs of a larger buffer (row stride > cols, frame stride > frame)."""
+    import ctypes as C
+    pkg, O = mods
+    from orb_slam2_comment_amd import capi
+    B, H, W, SH, SW = 3, 240, 320, 260, 352
+    big = np.zeros((B, SH, SW), np.uint8)
+    for b in range(B):
+        big[b, 10:10 + H, 16:16 + W] = synth_frame(40 + b, W, H)
+    ext = pkg.ORBextractor(400, 1.2, 6, 20, 7)
+    cap = ext.capacity(H, W)
+    kps = np.zeros((B, cap), pkg.KP_DTYPE); desc = np.zeros((B, cap, 32), np.uint8); n = np.zeros(B, np.int32)
+    first = big[0, 10:, 16:]
+    capi.check(capi.lib().orbhip_extract_batch(ext._h, first.ctypes.data_as(C.c_void_p), B, H, W, SW, SH * SW,
+                                               capi.ptr(kps), capi.ptr(desc), cap, capi.ptr(n)), "orbhip_extract_batch")
+    ora = O.OracleExtractor(400, 1.2, 6, 20, 7)
+    for b in range(B):
+        ok, od = ora.extract(np.ascontiguousarray(big[b, 10:10 + H, 16:16 + W]))
+        assert_kps_equal(kps[b, :n[b]], ok, "frame %d" % b)
+        assert np.array_equal(desc[b, :n[b]], od)
