@@ -237,6 +237,18 @@ int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int
                                   const orbhip_keypoint *keys_r, const uint8_t *desc_r, int nr,
                                   float mbf, float mb, float *u_right, float *depth, int *nmatches);
 
+/* Device-resident, batched Frame::ComputeStereoMatches over `pairs` stereo pairs: pair p uses frame l0 + p*ls of
+ * the left extractor's last batch (pyramid and rows of d_kps_l / d_desc_l / d_n_l) and frame r0 + p*rs of the right
+ * one (left and right may be the same handle holding an interleaved batch: l0=0, ls=2, r0=1, rs=2).  Arrays are in
+ * the extractor's output layout with stride `cap`.  Outputs: d_u_right / d_depth [pairs][cap] float (entries beyond
+ * the left frame's count are untouched), d_nmatches [pairs] int32.  Asynchronous on the matcher's stream; the caller
+ * orders it after the extractions (same stream, or orbhip_extractor_sync). */
+int orbhip_compute_stereo_matches_device(orbhip_matcher *m, orbhip_extractor *left, int l0, int ls,
+                                         orbhip_extractor *right, int r0, int rs, int pairs, const void *d_kps_l,
+                                         const void *d_desc_l, const void *d_n_l, const void *d_kps_r,
+                                         const void *d_desc_r, const void *d_n_r, int cap, float mbf, float mb,
+                                         void *d_u_right, void *d_depth, void *d_nmatches);
+
 #ifdef __cplusplus
 }
 #endif

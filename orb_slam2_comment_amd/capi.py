@@ -73,6 +73,8 @@ SYMBOLS = [
                                                        _vp, _i, _f, _vp, _vp]),
     ("orbhip_matcher_set_stream", _i, [_vp, _vp]),
     ("orbhip_matcher_sync", _i, [_vp]),
+    ("orbhip_compute_stereo_matches_device", _i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                                  _f, _f, _vp, _vp, _vp]),
     ("orbhip_compute_stereo_matches", _i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f,
                                            _f, _vp, _vp, _pi]),
 ]

@@ -610,9 +610,22 @@ struct StereoGeom {
     float mbf, mb;
 };
 
+// Batched stereo: pair p uses frame l0 + p*ls of the left arrays/pyramids and r0 + p*rs of the right ones.
+struct StereoBatch {
+    const int *n_l, *n_r;   // per-frame keypoint counts on the device, or null (use the nl / nr arguments)
+    int l0, ls, r0, rs;     // frame index mapping
+    int cap;                // keypoint stride per frame
+    unsigned fb_l, fb_r;    // pyramid bytes per frame of the two extractor handles
+};
+
 // row band of every right keypoint (Frame.cc:483-493)
-__global__ void k_stereo_rows(const orbhip_keypoint *__restrict__ kr, int nr, StereoGeom G, int2 *__restrict__ band)
+__global__ void k_stereo_rows(const orbhip_keypoint *__restrict__ kr, int nr, StereoGeom G, int2 *__restrict__ band,
+                              StereoBatch B)
 {
+    const int pair = blockIdx.y, fr = B.r0 + pair * B.rs;
+    kr += (size_t)fr * B.cap;
+    band += (size_t)pair * B.cap;
+    if (B.n_r) nr = min(B.n_r[fr], B.cap);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nr) return;
     const float kpY = kr[i].y;
@@ -626,9 +639,23 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbhip_keypoint *__r
                                                       const uint8_t *__restrict__ dr, int nr,
                                                       const int2 *__restrict__ band, StereoGeom G,
                                                       float *__restrict__ uRight, float *__restrict__ depth,
-                                                      int *__restrict__ sad)
+                                                      int *__restrict__ sad, StereoBatch B)
 {
     const int lane = threadIdx.x & 63;
+    {
+        const int pair = blockIdx.y, fl = B.l0 + pair * B.ls, fr = B.r0 + pair * B.rs;
+        kl += (size_t)fl * B.cap; dl += (size_t)fl * B.cap * 32;
+        kr += (size_t)fr * B.cap; dr += (size_t)fr * B.cap * 32;
+        band += (size_t)pair * B.cap;
+        uRight += (size_t)pair * B.cap; depth += (size_t)pair * B.cap; sad += (size_t)pair * B.cap;
+        if (B.n_l) nl = min(B.n_l[fl], B.cap);
+        if (B.n_r) nr = min(B.n_r[fr], B.cap);
+#pragma unroll
+        for (int l = 0; l < ORBHIP_MAX_LEVELS; ++l) {
+            G.left[l] += (size_t)fl * B.fb_l;
+            G.right[l] += (size_t)fr * B.fb_r;
+        }
+    }
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (iL >= nl) return;
     if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; sad[iL] = -1; }
@@ -734,10 +761,16 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbhip_keypoint *__r
 // median-based outlier cull (:626-639): thDist = 1.5f*1.4f*median of the SAD list sorted by
 // (dist, iL); entries with dist >= thDist are removed.
 __global__ __launch_bounds__(256) void k_stereo_cull(int nl, const int *__restrict__ sad, float *__restrict__ uRight,
-                                                     float *__restrict__ depth, int *__restrict__ out_n)
+                                                     float *__restrict__ depth, int *__restrict__ out_n, StereoBatch B)
 {
     __shared__ int s_nd, s_med, s_cnt;
     const int tid = threadIdx.x;
+    {
+        const int pair = blockIdx.x;
+        sad += (size_t)pair * B.cap; uRight += (size_t)pair * B.cap; depth += (size_t)pair * B.cap;
+        out_n += pair;
+        if (B.n_l) nl = min(B.n_l[B.l0 + pair * B.ls], B.cap);
+    }
     if (tid == 0) { s_nd = 0; s_med = 0; s_cnt = 0; }
     __syncthreads();
     int local = 0;
@@ -1155,6 +1188,50 @@ int orbhip_search_by_projection_points_device(orbhip_matcher *m, int pairs, cons
                          d_qdesc, d_nq, qcap, nnratio, 0, d_assign, d_nmatches);
 }
 
+int orbhip_compute_stereo_matches_device(orbhip_matcher *m, orbhip_extractor *left, int l0, int ls,
+                                         orbhip_extractor *right, int r0, int rs, int pairs, const void *d_kps_l,
+                                         const void *d_desc_l, const void *d_n_l, const void *d_kps_r,
+                                         const void *d_desc_r, const void *d_n_r, int cap, float mbf, float mb,
+                                         void *d_u_right, void *d_depth, void *d_nmatches)
+{
+    if (!m || !left || !right || pairs <= 0 || cap <= 0 || !d_kps_l || !d_desc_l || !d_n_l || !d_kps_r || !d_desc_r ||
+        !d_n_r || !d_u_right || !d_depth || !d_nmatches) return ORBHIP_E_ARG;
+    if (!left->bound || !right->bound || left->device != m->device || right->device != m->device ||
+        left->nlevels != right->nlevels || l0 < 0 || r0 < 0 || ls < 0 || rs < 0 ||
+        l0 + (pairs - 1) * ls >= left->last_batch || r0 + (pairs - 1) * rs >= right->last_batch) {
+        set_error("stereo: extractor handles do not hold the requested frames on device %d", m->device);
+        return ORBHIP_E_ARG;
+    }
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    StereoGeom G;
+    memset(&G, 0, sizeof(G));
+    G.nlevels = left->nlevels; G.nrows = left->G.lv[0].h; G.mbf = mbf; G.mb = mb;
+    for (int l = 0; l < G.nlevels; ++l) {
+        const LevelGeom &A = left->G.lv[l], &Bv = right->G.lv[l];
+        G.left[l] = left->d_pyr + A.plane_off + (size_t)kEdge * A.pitch + kPadL;
+        G.right[l] = right->d_pyr + Bv.plane_off + (size_t)kEdge * Bv.pitch + kPadL;
+        G.pitch_l[l] = A.pitch; G.pitch_r[l] = Bv.pitch; G.cols_r[l] = Bv.w;
+        G.sf[l] = left->sf[l]; G.isf[l] = left->isf[l];
+    }
+    for (int l = G.nlevels; l < ORBHIP_MAX_LEVELS; ++l) { G.left[l] = G.left[0]; G.right[l] = G.right[0]; }
+    void *p;
+    int rc;
+    if ((rc = scratch(m, S_ORD, (size_t)pairs * cap * sizeof(int2), &p))) return rc;
+    int2 *d_band = (int2 *)p;
+    if ((rc = scratch(m, S_CNT, (size_t)pairs * cap * sizeof(int), &p))) return rc;
+    int *d_sad = (int *)p;
+    const StereoBatch B = {(const int *)d_n_l, (const int *)d_n_r, l0, ls, r0, rs, cap, left->G.frame_bytes, right->G.frame_bytes};
+    hipLaunchKernelGGL(k_stereo_rows, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, (const orbhip_keypoint *)d_kps_r,
+                       cap, G, d_band, B);
+    hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, pairs), dim3(256), 0, m->stream, (const orbhip_keypoint *)d_kps_l,
+                       (const uint8_t *)d_desc_l, cap, (const orbhip_keypoint *)d_kps_r, (const uint8_t *)d_desc_r, cap, d_band,
+                       G, (float *)d_u_right, (float *)d_depth, d_sad, B);
+    hipLaunchKernelGGL(k_stereo_cull, dim3(pairs), dim3(256), 0, m->stream, cap, d_sad, (float *)d_u_right, (float *)d_depth,
+                       (int *)d_nmatches, B);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
 int orbhip_matcher_set_stream(orbhip_matcher *m, void *stream)
 {
     if (!m) return ORBHIP_E_ARG;
@@ -1219,10 +1296,11 @@ int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int
     int *d_sad = (int *)(d_depth + nl), *d_n = d_sad + nl;
     uint8_t *h_out;
     if ((rc = out_buffer(m, (size_t)(3 * nl + 1) * sizeof(float), &h_out))) return rc;
-    hipLaunchKernelGGL(k_stereo_rows, dim3((nr + 255) / 256), dim3(256), 0, m->stream, d_kr, nr, G, d_band);
+    const StereoBatch one = {nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(k_stereo_rows, dim3((nr + 255) / 256), dim3(256), 0, m->stream, d_kr, nr, G, d_band, one);
     hipLaunchKernelGGL(k_stereo_match, dim3((nl + 3) / 4), dim3(256), 0, m->stream, d_kl, d_dl, nl, d_kr, d_dr, nr, d_band,
-                       G, d_ur, d_depth, d_sad);
-    hipLaunchKernelGGL(k_stereo_cull, dim3(1), dim3(256), 0, m->stream, nl, d_sad, d_ur, d_depth, d_n);
+                       G, d_ur, d_depth, d_sad, one);
+    hipLaunchKernelGGL(k_stereo_cull, dim3(1), dim3(256), 0, m->stream, nl, d_sad, d_ur, d_depth, d_n, one);
     ORBHIP_HIP_CHECK(hipGetLastError());
     ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_ur, (size_t)(3 * nl + 1) * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));

@@ -180,6 +180,14 @@ class ORBmatcher:
             self._h, pairs, d_kps, d_desc, d_n, cap, d_u_right, d_taken, b[0], b[1], inv_w, inv_h, d_q, d_qdesc, d_nq,
             qcap, self.mfNNratio, d_assign, d_nmatches), "orbhip_search_by_projection_points_device")
 
+    def ComputeStereoMatchesDevice(self, ext_left, l0, ls, ext_right, r0, rs, pairs, d_kps_l, d_desc_l, d_n_l, d_kps_r,
+                                   d_desc_r, d_n_r, cap, mbf, mb, d_u_right, d_depth, d_nmatches):
+        """Batched, device-resident ComputeStereoMatches (all d_* are device pointers)."""
+        check(self._lib.orbhip_compute_stereo_matches_device(self._h, ext_left._h, l0, ls, ext_right._h, r0, rs, pairs,
+                                                             d_kps_l, d_desc_l, d_n_l, d_kps_r, d_desc_r, d_n_r, cap, mbf,
+                                                             mb, d_u_right, d_depth, d_nmatches),
+              "orbhip_compute_stereo_matches_device")
+
     # -- Frame::ComputeStereoMatches (src/Frame.cc:466-640) --------------------
     def ComputeStereoMatches(self, extractor_left, extractor_right, keys_l, desc_l, keys_r, desc_r, mbf, mb,
                              frame_l=0, frame_r=0):

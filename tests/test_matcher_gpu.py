@@ -353,3 +353,45 @@ def test_search_best_in_window_fuse_and_sim3(env, th, stereo, gate):
     obi, obd = O.search_best_in_window(ov, q, da, inv_sig2 if gate else None)
     assert np.array_equal(bi, obi) and np.array_equal(bd, obd)
     assert (bd <= 50).sum() > 50
+
+
+def test_device_batched_stereo_equals_host_api(env):
+    """orbhip_compute_stereo_matches_device on an interleaved (L0,R0,L1,R1,...) batch held by ONE extractor
+    handle == the host entry point pair by pair."""
+    import torch
+    pkg, M, O = env
+    dev = torch.device("cuda:0")
+    P, H, W = 3, 376, 1241
+    frames = []
+    for p in range(P):
+        l, r = synth_stereo(60 + p, W, H)
+        frames += [l, r]
+    frames = np.stack(frames)
+    B = 2 * P
+    ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    cap = ext.capacity(H, W)
+    d_img = torch.from_numpy(frames).to(dev)
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.int32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    ext.extract_batch_device(d_img.data_ptr(), B, H, W, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+    ext.sync()
+    d_ur = torch.full((P, cap), -7.0, dtype=torch.float32, device=dev)
+    d_dp = torch.full((P, cap), -7.0, dtype=torch.float32, device=dev)
+    d_nm = torch.zeros(P, dtype=torch.int32, device=dev)
+    mbf = float(np.float32(KITTI_BF)); mb = float(np.float32(KITTI_BF) / np.float32(KITTI_FX))
+    m = pkg.ORBmatcher()
+    m.ComputeStereoMatchesDevice(ext, 0, 2, ext, 1, 2, P, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(),
+                                 d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, mbf, mb, d_ur.data_ptr(),
+                                 d_dp.data_ptr(), d_nm.data_ptr())
+    m.sync()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28).copy().view(pkg.KP_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy(); n = d_n.cpu().numpy()
+    ur, dp, nm = d_ur.cpu().numpy(), d_dp.cpu().numpy(), d_nm.cpu().numpy()
+    for p in range(P):
+        nl, nr = int(n[2 * p]), int(n[2 * p + 1])
+        hn, hur, hdp = m.ComputeStereoMatches(ext, ext, kps[2 * p, :nl], desc[2 * p, :nl], kps[2 * p + 1, :nr],
+                                              desc[2 * p + 1, :nr], mbf, mb, frame_l=2 * p, frame_r=2 * p + 1)
+        assert hn == nm[p] and hn > 100
+        assert np.array_equal(ur[p, :nl], hur) and np.array_equal(dp[p, :nl], hdp)
+        assert np.all(ur[p, nl:] == -7.0)
