@@ -239,7 +239,43 @@ def main():
                 keep_alive.pop(0)
         torch.cuda.synchronize(dev)
         dtm = time.perf_counter() - t0
-        match_info = {"value": round(B * args.steps / dtm, 1), "unit": "frames/s",
+        # configs[2]-style stereo front-end: 32 interleaved (left, right) pairs per step through ONE extractor
+        # handle, then device-resident Frame::ComputeStereoMatches for the 32 pairs
+        from orb_slam2_comment_amd.synth import synth_stereo
+        st_frames = []
+        for p in range(8):
+            l, r = synth_stereo(1 + p, W, H)
+            st_frames += [l, r]
+        st_frames = np.stack([st_frames[i % 16] for i in range(B)])
+        d_simg = torch.from_numpy(st_frames).to(dev)
+        sext = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
+        sext.set_stream(cur.cuda_stream)
+        s_ur = torch.zeros((B // 2, cap), dtype=torch.float32, device=dev)
+        s_dp = torch.zeros((B // 2, cap), dtype=torch.float32, device=dev)
+        s_nm = torch.zeros(B // 2, dtype=torch.int32, device=dev)
+        mbf = 386.1448
+        mb = mbf / 718.856                         # Examples/Stereo/KITTI00-02.yaml:8,25
+
+        def stereo_step():
+            sext.extract_batch_device(d_simg.data_ptr(), B, H, W, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                      d_n.data_ptr(), d_st.data_ptr())
+            mt.ComputeStereoMatchesDevice(sext, 0, 2, sext, 1, 2, B // 2, d_kps.data_ptr(), d_desc.data_ptr(),
+                                          d_n.data_ptr(), d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, mbf, mb,
+                                          s_ur.data_ptr(), s_dp.data_ptr(), s_nm.data_ptr())
+        for _ in range(3):
+            stereo_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stereo_step()
+        torch.cuda.synchronize(dev)
+        dts = time.perf_counter() - t0
+        stereo_info = {"value": round(B // 2 * args.steps / dts, 1), "unit": "stereo pairs/s",
+                       "what": "extract left+right (32 interleaved pairs, one pipeline) + device-resident "
+                               "Frame::ComputeStereoMatches, fx 718.856 bf 386.1448",
+                       "ms_per_step": round(dts / args.steps * 1e3, 4),
+                       "mean_stereo_matches_per_pair": round(float(s_nm.float().mean().item()), 1)}
+        match_info = {"value": round(B * args.steps / dtm, 1), "unit": "frames/s", "stereo": stereo_info,
                       "what": "extract (64 frames) + device-resident SearchByProjection(CurrentFrame, LastFrame, th=15) "
                               "for the 32 (2k, 2k+1) pairs of each step; queries built on the GPU",
                       "ms_per_step": round(dtm / args.steps * 1e3, 4),
