@@ -344,19 +344,16 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         const int total = sh * SW;
         for (int i0 = 0; i0 < total; i0 += 64 * U) {
             uint32_t v[U];
+            // branch-free: indices are clamped instead of predicated.  Margin / spare dwords receive a copy of a
+            // neighbouring dword; they are only ever read on behalf of centres outside the detection rectangle.
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int i = i0 + u * 64 + lane;
-                const int y = (i * F.div_magic) >> 20, wx = i - y * SW;
-                v[u] = 0;
-                if (i < total && wx >= 1 && wx <= ndw)
-                    v[u] = *reinterpret_cast<const uint32_t *>(roi + (size_t)(cd.y0 + y) * L.pitch + gxb + 4 * (wx - 1));
+                const int i = min(i0 + u * 64 + lane, total - 1);
+                const int y = (i * F.div_magic) >> 20, wx = min(max(i - y * SW, 1), ndw);
+                v[u] = *reinterpret_cast<const uint32_t *>(roi + (size_t)(cd.y0 + y) * L.pitch + gxb + 4 * (wx - 1));
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + u * 64 + lane;
-                if (i < total) simg[i] = v[u];
-            }
+            for (int u = 0; u < U; ++u) simg[min(i0 + u * 64 + lane, total - 1)] = v[u];
         }
     }
     for (int i = lane; i < (dh + 2) * SW; i += 64) sscore[i] = 0;
