@@ -395,3 +395,35 @@ def test_device_batched_stereo_equals_host_api(env):
         assert hn == nm[p] and hn > 100
         assert np.array_equal(ur[p, :nl], hur) and np.array_equal(dp[p, :nl], hdp)
         assert np.all(ur[p, nl:] == -7.0)
+
+
+def test_matcher_golden_fixtures(env):
+    """Committed oracle outputs (tests/golden/make_golden.py): the GPU path must reproduce them without the oracle."""
+    import os
+    pkg, M, O = env
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "match_golden.npz"))
+    W, H, nf = 640, 480, 800
+    ext = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    k1, d1 = ext(synth_frame(21, W, H))
+    k2, d2 = ext(synth_frame(21, W, H, shift_xy=(4, 0)))
+    sf = ext.GetScaleFactors()
+    b = (0.0, 0.0, float(W), float(H))
+    F1, F2 = pkg.FrameView(k1, d1, sf, b), pkg.FrameView(k2, d2, sf, b)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    n, m12, _ = pkg.ORBmatcher(0.9, True).SearchForInitialization(F1, F2, prev, 100)
+    assert n == int(g["init_n"]) and np.array_equal(m12, g["init_m12"])
+    q = np.zeros(len(k1), pkg.QUERY_DTYPE)
+    q["valid"] = 1; q["u"] = k1["x"] + 4; q["v"] = k1["y"]; q["radius"] = 15 * sf[k1["octave"]]
+    q["min_level"] = k1["octave"] - 1; q["max_level"] = k1["octave"] + 1; q["angle"] = k1["angle"]
+    q["observed"] = np.arange(len(k1)) % 3 != 0
+    n, a = pkg.ORBmatcher(0.9, True).SearchByProjectionFrame(F2, q, d1)
+    assert n == int(g["proj_n"]) and np.array_equal(a, g["proj_assign"])
+    q["radius"] = 4.0 * sf[k1["octave"]]; q["max_level"] = k1["octave"]
+    n, a = pkg.ORBmatcher(0.8, True).SearchByProjectionPoints(F2, q, d1)
+    assert n == int(g["points_n"]) and np.array_equal(a, g["points_assign"])
+    left, right = synth_stereo(22, W, H)
+    eL, eR = pkg.ORBextractor(nf, 1.2, 8, 20, 7), pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    kl, dl = eL(left); kr, dr = eR(right)
+    mbf = float(np.float32(386.1448)); mb = float(np.float32(386.1448) / np.float32(718.856))
+    n, ur, dp = pkg.ORBmatcher().ComputeStereoMatches(eL, eR, kl, dl, kr, dr, mbf, mb)
+    assert n == int(g["stereo_n"]) and np.array_equal(ur, g["stereo_ur"]) and np.array_equal(dp, g["stereo_depth"])

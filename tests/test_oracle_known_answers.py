@@ -266,3 +266,32 @@ def test_extract_is_deterministic_and_translation_consistent(oracle):
     # flat image -> no corners at all
     kf, _ = e.extract(np.full((240, 320), 128, np.uint8))
     assert len(kf) == 0
+
+
+def test_oracle_reproduces_committed_golden_vectors(oracle):
+    """Regression pin: the committed fixtures (tests/golden/make_golden.py) equal today's oracle output."""
+    import os
+    import zlib
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "extract_golden.npz"))
+    for key in sorted(k[:-4] for k in g.files if k.endswith("_kps")):
+        seed, W, H, nf = (int(v) for v in key.split("_")[1:])
+        if W * H > 400000:
+            continue                      # keep the CPU suite short: the small fixtures suffice here
+        e = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+        k, d = e.extract(synth_frame(seed, W, H))
+        gk = np.frombuffer(zlib.decompress(g[key + "_kps"].tobytes()), oracle.KP_DTYPE)
+        gd = np.frombuffer(zlib.decompress(g[key + "_desc"].tobytes()), np.uint8).reshape(-1, 32)
+        assert len(k) == len(gk) and all(np.array_equal(k[f], gk[f]) for f in k.dtype.names), key
+        assert np.array_equal(d, gd), key
+    m = np.load(os.path.join(os.path.dirname(__file__), "golden", "match_golden.npz"))
+    W, H, nf = 640, 480, 800
+    e = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+    k1, d1 = e.extract(synth_frame(21, W, H))
+    k2, d2 = e.extract(synth_frame(21, W, H, shift_xy=(4, 0)))
+    sf = e.tables()["scale"]
+    keep = []
+    b = (0.0, 0.0, float(W), float(H))
+    f1, f2 = oracle.make_frame(k1, d1, None, b, sf, keep), oracle.make_frame(k2, d2, None, b, sf, keep)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    n, m12, _ = oracle.search_for_initialization(f1, f2, prev, 100, 0.9, True)
+    assert n == int(m["init_n"]) and np.array_equal(m12, m["init_m12"])
