@@ -1035,6 +1035,20 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
     const size_t fo = (size_t)b * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
     const uint8_t *c = pyr + fo + (size_t)ky * L.pitch + kx;
 
+    // The 37x37 blurred patch the descriptor samples (|rotated offset| <= 18) is fetched NOW, as aligned dwords, into
+    // this wavefront's LDS tile, together with the 12 disc pixels: one memory round trip instead of two (the taps'
+    // addresses depend on the angle, the patch does not).
+    __shared__ uint32_t spatch[4][37 * 11];
+    uint32_t *patch = spatch[threadIdx.x >> 6];
+    const int xs = (kx - 18) & ~3;                       // dword-aligned ROI column of patch column 0
+    const uint8_t *bb = blur + fo + (size_t)(ky - 18) * L.pitch + xs;
+    uint32_t pv[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        const int idx = min(u * 64 + lane, 37 * 11 - 1);
+        const int r = (idx * 5958) >> 16, cdw = idx - r * 11;   // idx / 11 for idx < 407
+        pv[u] = *reinterpret_cast<const uint32_t *>(bb + (size_t)r * L.pitch + 4 * cdw);
+    }
     int m10 = 0, m01 = 0;
     int pix[12];
 #pragma unroll
@@ -1042,6 +1056,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
         const int u = (signed char)(duv[i] & 0xff), v = (signed char)(duv[i] >> 8);
         pix[i] = c[v * L.pitch + u];
     }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) patch[min(u * 64 + lane, 37 * 11 - 1)] = pv[u];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int u = (signed char)(duv[i] & 0xff), v = (signed char)(duv[i] >> 8);
@@ -1055,7 +1071,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, bsn;
     det_sincos(__fmul_rn(angle, factorPI), &a, &bsn);
-    const uint8_t *cb = blur + fo + (size_t)ky * L.pitch + kx;
+    __builtin_amdgcn_wave_barrier();                     // the tile is private to this wavefront; DS ops are in order
+    const uint8_t *cb = reinterpret_cast<const uint8_t *>(patch) + 18 * 44 + (kx - xs);   // patch byte of the keypoint
     unsigned long long bits[4];
     int t0v[4], t1v[4];
 #pragma unroll
@@ -1067,8 +1084,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, bsn)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, bsn), __fmul_rn(py1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, bsn)));
-        t0v[j] = cb[r0 * L.pitch + c0];
-        t1v[j] = cb[r1 * L.pitch + c1];
+        t0v[j] = cb[r0 * 44 + c0];
+        t1v[j] = cb[r1 * 44 + c1];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) bits[j] = __ballot(t0v[j] < t1v[j]);
