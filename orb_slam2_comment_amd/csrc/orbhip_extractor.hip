@@ -1421,7 +1421,9 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
         return ORBHIP_E_HIP;
     }
     e->stream = e->own_stream;
-    if (hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+    int prio_lo = 0, prio_hi = 0;   // the blur is filler work: lowest priority, so FAST / octree dispatch first
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&e->aux_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming) != hipSuccess) {
         set_error("aux stream/event creation failed");
