@@ -148,26 +148,46 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ 
                                                     size_t frame_stride, uint8_t *__restrict__ pyr,
                                                     PyrGeom G)
 {
+    // one thread = 16 bytes of the padded destination row (one uint4 store).  Interior groups read their 16
+    // source bytes as five aligned dwords re-aligned with v_alignbyte_b32 (image rows have an odd stride);
+    // groups touching the REFLECT_101 frame or the row ends go byte by byte.
     const LevelGeom L = G.lv[0];
-    const int words = L.pitch >> 2;
+    const int quads = L.pitch >> 4;
     int bx, fr;
     xcd_remap(bx, fr);
     const int idx = bx * 256 + threadIdx.x;
-    if (idx >= words * L.prows) return;
-    const int py = idx / words, pw = idx - py * words;
+    if (idx >= quads * L.prows) return;
+    const int py = idx / quads, pq = idx - py * quads;
     const uint8_t *src = images + (size_t)fr * frame_stride;
     uint8_t *dst = pyr + (size_t)fr * G.frame_bytes + L.plane_off;
     const int sy = reflect101(py - kEdge, L.h);
     const uint8_t *srow = src + (size_t)sy * stride;
-    uint32_t out = 0;
+    const int x0 = pq * 16 - kPadL;
+    uint32_t out[4];
+    if (x0 >= 16 && x0 + 19 < L.w) {
+        const uint8_t *p = srow + x0;
+        const unsigned al = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p - al);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+        out[0] = __builtin_amdgcn_alignbyte(d1, d0, al);
+        out[1] = __builtin_amdgcn_alignbyte(d2, d1, al);
+        out[2] = __builtin_amdgcn_alignbyte(d3, d2, al);
+        out[3] = __builtin_amdgcn_alignbyte(d4, d3, al);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int x = pw * 4 + k - kPadL;
-        uint32_t v = 0;
-        if (x >= -kEdge && x < L.w + kEdge) v = srow[reflect101(x, L.w)];
-        out |= v << (8 * k);
+        for (int w = 0; w < 4; ++w) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x0 + 4 * w + k;
+                uint32_t v = 0;
+                if (x >= -kEdge && x < L.w + kEdge) v = srow[reflect101(x, L.w)];
+                acc |= v << (8 * k);
+            }
+            out[w] = acc;
+        }
     }
-    *reinterpret_cast<uint32_t *>(dst + (size_t)py * L.pitch + pw * 4) = out;
+    *reinterpret_cast<uint4 *>(dst + (size_t)py * L.pitch + pq * 16) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 // Resize tables (host-built, OpenCV fixed-point): per destination column sx[x] and the
@@ -1322,12 +1342,11 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     const bool prof = e->profiling;
     hipEvent_t *ev = prof ? &e->ev[(size_t)(e->prof_calls % orbhip_extractor::kProfRing) * orbhip_extractor::kProfEv] : nullptr;
     int *status = d_status ? d_status : e->d_status;
-    hipStream_t s2 = e->aux_stream;
     hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
     if (prof) hipEventRecord(ev[0], s);
     {
         const LevelGeom &L = G.lv[0];
-        int n = (L.pitch >> 2) * L.prows;
+        int n = (L.pitch >> 4) * L.prows;
         hipLaunchKernelGGL(k_pyr_level0, dim3((n + 255) / 256, batch), dim3(256), 0, s, d_images, stride,
                            frame_stride, e->d_pyr, G);
         for (int l = 1; l < G.nlevels; ++l) {
@@ -1337,15 +1356,6 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         }
     }
     if (prof) hipEventRecord(ev[1], s);
-    // fork: the blur only needs the pyramid; it is HBM-bound while FAST is VALU-bound and the octree is
-    // latency-bound, so it runs beside them on the auxiliary stream and joins before the descriptors
-    hipEventRecord(e->ev_pyr, s);
-    hipStreamWaitEvent(s2, e->ev_pyr, 0);
-    if (prof) hipEventRecord(ev[6], s2);
-    hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s2, e->d_pyr, e->d_blur, G,
-                       e->d_tiles, e->blurw);
-    if (prof) hipEventRecord(ev[7], s2);
-    hipEventRecord(e->ev_blur, s2);
     if (G.ncells_total > 0)
         hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, batch), dim3(64), (size_t)e->fast_lds_bytes, s, e->d_pyr, G,
                            e->d_cells, e->d_cell_cnt, e->d_cell_kp, e->fast_lds);
@@ -1357,7 +1367,11 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         hipLaunchKernelGGL(k_octree<2048>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
                            e->d_keys, e->d_knode, e->d_sel, e->d_sel_cnt, status);
     if (prof) hipEventRecord(ev[3], s);
-    hipStreamWaitEvent(s, e->ev_blur, 0);   // join
+    // The blur only needs the pyramid.  Forking it onto a second stream beside FAST/octree was measured: it buys
+    // nothing once two pipelines (handles) run concurrently and makes throughput depend on how the runtime maps
+    // streams to hardware queues (122 k vs 136 k frames/s run to run), so it stays in order on this stream.
+    hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, e->d_pyr, e->d_blur, G,
+                       e->d_tiles, e->blurw);
     if (prof) hipEventRecord(ev[4], s);
     hipLaunchKernelGGL(k_orient_describe, dim3((G.kp_cap_total + 3) / 4, batch), dim3(256), 0, s, e->d_pyr, e->d_blur,
                        G, e->d_sel, e->d_sel_cnt, e->d_disc, e->d_pattern, d_kps, d_desc, cap, d_n, status);
@@ -1421,15 +1435,6 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
         return ORBHIP_E_HIP;
     }
     e->stream = e->own_stream;
-    int prio_lo = 0, prio_hi = 0;   // the blur is filler work: lowest priority, so FAST / octree dispatch first
-    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (hipStreamCreateWithPriority(&e->aux_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_pyr, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_blur, hipEventDisableTiming) != hipSuccess) {
-        set_error("aux stream/event creation failed");
-        orbhip_extractor_destroy(e);
-        return ORBHIP_E_HIP;
-    }
     // disc offsets in the reference's traversal order (order is irrelevant for integer sums)
     DiscTab dt; memset(&dt, 0, sizeof(dt));   // padding entries (u = v = 0) contribute 0 to both moments
     int nd = 0;
@@ -1460,9 +1465,6 @@ void orbhip_extractor_destroy(orbhip_extractor *e)
     if (e->h_in) hipHostFree(e->h_in);
     if (e->h_out) hipHostFree(e->h_out);
     for (hipEvent_t v : e->ev) hipEventDestroy(v);
-    if (e->aux_stream) { hipStreamSynchronize(e->aux_stream); hipStreamDestroy(e->aux_stream); }
-    if (e->ev_pyr) hipEventDestroy(e->ev_pyr);
-    if (e->ev_blur) hipEventDestroy(e->ev_blur);
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -1703,9 +1705,8 @@ int orbhip_extractor_stage_times(orbhip_extractor *e, float us[6])
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
     const long n = std::min<long>(e->prof_calls, orbhip_extractor::kProfRing);
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    // stage -> (begin, end) event of the set: pyramid, fast, octree on the main stream; blur on the
-    // auxiliary stream (concurrent with fast + octree); describe after the join; whole call
-    static const int span[6][2] = {{0, 1}, {1, 2}, {2, 3}, {6, 7}, {4, 5}, {0, 5}};
+    // stage -> (begin, end) event of the set, all on the launch stream
+    static const int span[6][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {0, 5}};
     for (long c = 0; c < n; ++c) {
         hipEvent_t *ev = &e->ev[(size_t)c * orbhip_extractor::kProfEv];
         for (int i = 0; i < 6; ++i) {

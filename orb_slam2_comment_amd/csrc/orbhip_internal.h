@@ -27,10 +27,8 @@ struct orbhip_extractor {
     orbhip::BlurW blurw;
     hipStream_t stream = nullptr;       // stream every launch of this handle goes to
     hipStream_t own_stream = nullptr;   // created with the handle; `stream` may be re-pointed
-    hipStream_t aux_stream = nullptr;   // blur runs here, concurrently with FAST + octree
-    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;   // fork/join of the aux stream
     // profiling: ring of event sets (kProfEv events per extract call), averaged on read-out
-    static constexpr int kProfEv = 8;
+    static constexpr int kProfEv = 6;
     static constexpr int kProfRing = 256;
     std::vector<hipEvent_t> ev;         // kProfRing * 6, created lazily
     bool profiling = false;
