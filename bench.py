@@ -128,8 +128,10 @@ def main():
     d_img = torch.from_numpy(frames).to(dev)
 
     Hn = max(1, args.handles)
-    assert B % Hn == 0, "--frames-per-gpu must be a multiple of --handles"
-    Bh = B // Hn
+    # frames of the per-GPU batch are split as evenly as possible between the pipelines
+    splits = [B // Hn + (1 if h < B % Hn else 0) for h in range(Hn)]
+    offs = [sum(splits[:h]) for h in range(Hn)]
+    Bh = splits[0]
     exts, streams = [], []
     for h in range(Hn):
         e = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
@@ -147,9 +149,9 @@ def main():
 
     def step():
         for h, e in enumerate(exts):
-            sl = slice(h * Bh, (h + 1) * Bh)
-            e.extract_batch_device(d_img[sl].data_ptr(), Bh, H, W, d_kps[sl].data_ptr(), d_desc[sl].data_ptr(), cap,
-                                   d_n[sl].data_ptr(), d_st[sl].data_ptr())
+            sl = slice(offs[h], offs[h] + splits[h])
+            e.extract_batch_device(d_img[sl].data_ptr(), splits[h], H, W, d_kps[sl].data_ptr(), d_desc[sl].data_ptr(),
+                                   cap, d_n[sl].data_ptr(), d_st[sl].data_ptr())
         if world > 1:
             for st in streams[1:] if Hn > 1 else []:
                 torch.cuda.current_stream(dev).wait_stream(st)

@@ -387,6 +387,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     const int magic = ((1 << 20) + ngrp - 1) / ngrp;    // exact floor(i/ngrp) for i < 4096
     const int tmin = G.min_th;
     const i16x2_t T2 = {(short)tmin, (short)tmin};
+    const int list_dummy = F.list_words * 2 - 1;        // last uint16 of the list region: never a real entry
 
     // ---- 2. dense pre-test (packed int16, two pixels per operation), survivors -> slist ----
     int nsurv = 0;
@@ -425,7 +426,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         for (int j = 0; j < 4; ++j) {
             const bool pre = (keepm >> j) & 1u;
             const unsigned long long bm = __ballot(pre);
-            if (pre) slist[nsurv + lane_prefix(bm)] = (unsigned short)((y << 7) | (4 * g + j));
+            // branch-free append: lanes without a survivor write the scratch slot behind the list
+            slist[pre ? nsurv + lane_prefix(bm) : list_dummy] = (unsigned short)((y << 7) | (4 * g + j));
             nsurv += __popcll(bm);
         }
     }
