@@ -338,7 +338,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     uint32_t *simg = lds;                                   // staged sub-image
     uint32_t *sscore = lds + F.img_words;                   // score map, 1-px zero halo rows
     unsigned short *slist = reinterpret_cast<unsigned short *>(sscore + F.score_words);  // (y<<7)|col
-    uint32_t *sfinal = sscore + F.score_words + F.list_words;                            // NMS survivors
+    // NMS survivors: the staged image is dead once the scores exist, so the finals reuse its LDS when they fit
+    uint32_t *sfinal = F.final_in_img ? simg : sscore + F.score_words + F.list_words;
 
     int cell, fr;
     xcd_remap(cell, fr);
@@ -1282,7 +1283,8 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         F.img_words = msh * F.strideW;
         F.score_words = (mdh + 2) * F.strideW;
         F.list_words = (mdw * mdh + 1) / 2 + 1;           // uint16 list: every pixel may pass the pre-test
-        e->fast_lds_bytes = (F.img_words + F.score_words + F.list_words + slot_cap + 64) * 4;
+        F.final_in_img = (slot_cap + 64 <= F.img_words) ? 1 : 0;
+        e->fast_lds_bytes = (F.img_words + F.score_words + F.list_words + (F.final_in_img ? 0 : slot_cap + 64)) * 4;
         if (F.strideW * 4 > 127 || msh * F.strideW >= 8192) { set_error("cell geometry exceeds the FAST kernel limits"); return ORBHIP_E_SIZE; }
     }
     G.frame_bytes = off;

@@ -13,6 +13,7 @@ struct FastLds {
     int strideW;      // row stride in dwords (odd): 1 margin dword + staged dwords + 1 spare
     int div_magic;    // (i * div_magic) >> 20 == i / strideW for i < 8192
     int img_words, score_words, list_words;
+    int final_in_img; // NMS survivors alias the staged image (dead by then) when slot_cap + 64 <= img_words
 };
 struct DiscTab { unsigned short uv[768]; };  // 749 disc offsets (u | v << 8), zero padded to 12 x 64
 }  // namespace orbhip
