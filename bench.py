@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL; default) or gloo (rehearsal of the multi-rank control flow on one GPU: "
                          "all ranks share cuda:0 and the gather goes through host memory)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: run the multi-rank code path (RCCL init, gather, all_reduce) even with one rank")
     ap.add_argument("--handles", type=int, default=2,
                     help="extractor handles per GPU; the per-GPU batch is split evenly between them and their "
                          "pipelines run concurrently on separate HIP streams")
@@ -100,7 +102,12 @@ def main():
     rehearsal = world > 1 and args.dist_backend == "gloo"
     if rehearsal:
         local_rank = 0
-    if world > 1:
+    multi = world > 1 or args.force_dist          # take the distributed code path
+    if args.force_dist and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -111,7 +118,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from orb_slam2_comment_amd import ORBextractor
-    from orb_slam2_comment_amd.sharding import gather_to_rank0, shard_indices
+    from orb_slam2_comment_amd.sharding import gather_into, gather_to_rank0, shard_indices
     from orb_slam2_comment_amd.synth import synth_frame
 
     B = args.frames_per_gpu
@@ -147,28 +154,45 @@ def main():
     d_st = torch.zeros(B, dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)
 
+    # multi-rank: outputs are double-buffered and the RCCL gather of step k runs on its own stream beside the
+    # extraction of step k+1; rank 0 gathers into preallocated rank-major buffers (no per-step allocation)
+    nbuf = 2 if multi and not rehearsal else 1
+    obuf = [(d_kps, d_desc, d_n, d_st)]
+    for _ in range(nbuf - 1):
+        obuf.append((torch.zeros_like(d_kps), torch.zeros_like(d_desc), torch.zeros_like(d_n), torch.zeros_like(d_st)))
+    gstream = torch.cuda.Stream(dev) if nbuf == 2 else None
+    gdone = [None, None]
+    gout = None
+    if nbuf == 2 and rank == 0:
+        gout = [torch.zeros((world,) + tuple(t.shape), dtype=t.dtype, device=dev) for t in (d_kps, d_desc, d_n)]
+    stepno = [0]
+
     def step():
+        k = stepno[0] % nbuf
+        stepno[0] += 1
+        ok, od, on, ost = obuf[k]
+        if gdone[k] is not None:                 # the gather that last read this buffer must be finished
+            for st in streams:
+                st.wait_event(gdone[k])
         for h, e in enumerate(exts):
             sl = slice(offs[h], offs[h] + splits[h])
-            e.extract_batch_device(d_img[sl].data_ptr(), splits[h], H, W, d_kps[sl].data_ptr(), d_desc[sl].data_ptr(),
-                                   cap, d_n[sl].data_ptr(), d_st[sl].data_ptr())
-        if world > 1:
-            for st in streams[1:] if Hn > 1 else []:
-                torch.cuda.current_stream(dev).wait_stream(st)
-            if Hn > 1:
-                torch.cuda.current_stream(dev).wait_stream(streams[0])
+            e.extract_batch_device(d_img[sl].data_ptr(), splits[h], H, W, ok[sl].data_ptr(), od[sl].data_ptr(),
+                                   cap, on[sl].data_ptr(), ost[sl].data_ptr())
+        if multi:
             if rehearsal:
                 torch.cuda.synchronize(dev)
-                return gather_to_rank0(d_kps.cpu(), d_desc.cpu(), d_n.cpu())
-            out = gather_to_rank0(d_kps, d_desc, d_n)
-            if Hn > 1:                       # the next extraction must not overwrite what the gather reads
-                for st in streams:
-                    st.wait_stream(torch.cuda.current_stream(dev))
+                return gather_to_rank0(ok.cpu(), od.cpu(), on.cpu())
+            for st in streams:
+                gstream.wait_stream(st)
+            with torch.cuda.stream(gstream):
+                out = gather_into(gout, (ok, od, on))
+                gdone[k] = gstream.record_event()
             return out
         return None
 
     def barrier():
-        if world > 1:
+        torch.cuda.synchronize(dev)              # drains the extraction streams and the gather stream
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -186,7 +210,7 @@ def main():
     stage = {k: sum(st[k] for st in stages) / len(stages) for k in stages[0]}
     for e in exts:
         e.set_profiling(False)
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -198,7 +222,7 @@ def main():
     # (ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th=15), src/Tracking.cc:880-885) with queries
     # built on the GPU from the predecessor's keypoints (synthetic 3-px motion), 32 pairs per step.
     match_info = None
-    if not args.no_match and world == 1:
+    if not args.no_match and world == 1 and not multi:
         from orb_slam2_comment_amd import ORBmatcher
         mt = ORBmatcher(0.9, True, device=local_rank)
         cur = torch.cuda.current_stream(dev)
@@ -332,7 +356,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -11,6 +11,21 @@ def shard_indices(num_frames, rank, world_size):
     return list(range(rank, num_frames, world_size))
 
 
+def gather_into(outs, tensors, dst=0, group=None):
+    """Allocation-free form for steady-state loops: `outs` (rank `dst` only) are preallocated tensors of shape
+    [W, *t.shape] per input tensor; rank w's shard lands in outs[i][w] (rank-major: global frame g = local
+    index g // W of rank g % W).  Returns `outs` on `dst`, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    for i, t in enumerate(tensors):
+        t = t.contiguous()
+        if rank == dst:
+            dist.gather(t, gather_list=[outs[i][w] for w in range(world)], dst=dst, group=group)
+        else:
+            dist.gather(t, gather_list=None, dst=dst, group=group)
+    return outs if rank == dst else None
+
+
 def gather_to_rank0(kps, desc, counts, dst=0, group=None):
     """kps: int32 [b, cap, 7] (the 28-byte KeyPoint records viewed as 7 dwords),
     desc: uint8 [b, cap, 32], counts: int32 [b]; same shapes on every rank.
