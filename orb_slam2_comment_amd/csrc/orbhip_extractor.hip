@@ -389,6 +389,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     const int tmin = G.min_th;
     const i16x2_t T2 = {(short)tmin, (short)tmin};
     const int list_dummy = F.list_words * 2 - 1;        // last uint16 of the list region: never a real entry
+    const uint32_t vm_first = (0xfu << (c_lo & 3)) & 0xfu;       // valid centres of the first group of a row
+    const uint32_t vm_last = 0xfu >> (3 - ((c_hi - 1) & 3));     // ... and of the last one
 
     // ---- 2. dense pre-test (packed int16, two pixels per operation), survivors -> slist ----
     int nsurv = 0;
@@ -398,9 +400,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         const int g = g_lo + it - y * ngrp;
         uint32_t keepm = 0;
         if (it < nwork) {
-            const uint32_t *p = &simg[(y + 3) * SW + g - 1];
+            const int rb = __mul24(y, SW) + g;              // dword index of (row y, group g)
+            const uint32_t *p = &simg[rb + 3 * SW - 1];
             const uint32_t c0 = p[0], c1 = p[1], c2 = p[2];
-            const uint32_t up = simg[y * SW + g], dn = simg[(y + 6) * SW + g];
+            const uint32_t up = simg[rb], dn = simg[rb + 6 * SW];
             const uint32_t e4 = __builtin_amdgcn_alignbyte(c2, c1, 3);    // ring pixel 4  (x+3): bytes 7..10
             const uint32_t e12 = __builtin_amdgcn_alignbyte(c1, c0, 1);   // ring pixel 12 (x-3): bytes 1..4
             uint32_t m[2];
@@ -415,20 +418,18 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                 const i16x2_t s1 = T2 - br, s2 = dk + T2;   // negative <=> br > t, dk < -t
                 m[h] = (__builtin_bit_cast(uint32_t, s1) | __builtin_bit_cast(uint32_t, s2)) & 0x80008000u;
             }
-            const int col0 = 4 * g;
             keepm = ((m[0] >> 15) & 1u) | ((m[0] >> 30) & 2u) | ((m[1] >> 13) & 4u) | ((m[1] >> 28) & 8u);
-            // mask centres outside the detection rectangle
-            uint32_t vm = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) vm |= (uint32_t)(col0 + j >= c_lo && col0 + j < c_hi) << j;
-            keepm &= vm;
+            // centres outside the detection rectangle: only the first / last group of a row is partial
+            keepm &= (g == g_lo ? vm_first : 0xfu) & (g == g_hi ? vm_last : 0xfu);
         }
+        const uint32_t ent = (uint32_t)((y << 7) | (4 * g));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool pre = (keepm >> j) & 1u;
             const unsigned long long bm = __ballot(pre);
             // branch-free append: lanes without a survivor write the scratch slot behind the list
-            slist[pre ? nsurv + lane_prefix(bm) : list_dummy] = (unsigned short)((y << 7) | (4 * g + j));
+            const int pos = nsurv + lane_prefix(bm);
+            slist[pre ? pos : list_dummy] = (unsigned short)(ent + j);
             nsurv += __popcll(bm);
         }
     }
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         if (i < nsurv) {
             e = slist[i];
             const int y = e >> 7, col = e & 127;
-            const uint8_t *c = img8 + (y + 3) * SB + col;
+            const uint8_t *c = img8 + __mul24(y + 3, SB) + col;
             const int v = c[0];
             int d[16];
             d[0] = v - c[3 * SB];       d[1] = v - c[3 * SB + 1];
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             brn = min3i(brn, min3i(mx9[9], mx9[10], mx9[11]), min3i(mx9[12], mx9[13], min(mx9[14], mx9[15])));
             const int sc = max(dark, -brn) - 1;       // cornerScore; corner at minTh <=> S >= minTh
             isc = sc >= tmin;
-            if (isc) score8[(y + 1) * SB + col] = (uint8_t)min(sc, 255);
+            if (isc) score8[__mul24(y + 1, SB) + col] = (uint8_t)min(sc, 255);
         }
         const unsigned long long m = __ballot(isc);
         if (isc) slist[ncorn + lane_prefix(m)] = e;     // write index <= read index: in place is safe
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         if (i < ncorn) {
             const unsigned short e = slist[i];
             const int y = e >> 7, col = e & 127;
-            const uint8_t *s = score8 + (y + 1) * SB + col;
+            const uint8_t *s = score8 + __mul24(y + 1, SB) + col;
             const int v = s[0];
             keep = v > s[-1] && v > s[1] && v > s[-SB - 1] && v > s[-SB] && v > s[-SB + 1] &&
                    v > s[SB - 1] && v > s[SB] && v > s[SB + 1];
