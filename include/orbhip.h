@@ -25,6 +25,9 @@
  *                                     (src/ORBmatcher.cc:290-403, loop closing)
  *   orbhip_search_best_in_window      inner search of ORBmatcher::Fuse x2 (src/ORBmatcher.cc:825-1100) and of both
  *                                     directions of SearchBySim3 (:1102-1326)
+ *   orbhip_search_by_bow              ORBmatcher::SearchByBoW(KeyFrame*,Frame&,..) (src/ORBmatcher.cc:159-288) and
+ *                                     SearchByBoW(KeyFrame*,KeyFrame*,..) (:522-655); vocabulary node ids are inputs
+ *   orbhip_search_for_triangulation   ORBmatcher::SearchForTriangulation (:657-823) incl. CheckDistEpipolarLine (:140-157)
  */
 #ifndef ORBHIP_H
 #define ORBHIP_H
@@ -205,6 +208,37 @@ int orbhip_search_by_projection_sim3(orbhip_matcher *m, const orbhip_frame_view 
 int orbhip_search_best_in_window(orbhip_matcher *m, const orbhip_frame_view *kf, const orbhip_query *q,
                                  const uint8_t *qdesc, int nq, int chi2_gate, const float *inv_level_sigma2,
                                  int32_t *best_idx, int32_t *best_dist);
+
+/* Vocabulary-guided matching.  The DBoW2 vocabulary lookup (Frame::ComputeBoW, src/Frame.cc:395-403) stays with
+ * the caller; what arrives here is the FeatureVector flattened to one node id per keypoint (node1[n1], node2[n2]:
+ * the NodeId at levelsup = 4 that DBoW2 stored the feature under, ORBHIP_NO_NODE if absent).  Node lists are visited
+ * in ascending node id and ascending feature index, which is how DBoW2 builds and std::map iterates them.
+ *
+ * orbhip_search_by_bow: for every f1 keypoint with valid1 != 0 (map point exists and is not bad; null = all), best
+ * and second-best Hamming distance among the f2 keypoints of the same node that are neither blocked2 (null = none;
+ * key-frame overload: "no good map point in pKF2") nor matched by an earlier f1 keypoint; accepted when
+ * best <= max_dist (TH_LOW = 50 for the Frame overload :262, 49 for the key-frame overload's strict "<" :598) and
+ * (float)best < nnratio*(float)second; rotation-histogram cull when check_ori.  matches12[n1] = f2 index or -1
+ * (the Frame overload's vpMapPointMatches[idx2] = map point of idx1 is the inverse of this 1:1 map).
+ * n1, n2 <= 4096 (ORBHIP_E_CAPACITY otherwise). */
+#define ORBHIP_NO_NODE 0xffffffffu
+int orbhip_search_by_bow(orbhip_matcher *m, const orbhip_frame_view *f1, const uint32_t *node1, const uint8_t *valid1,
+                         const orbhip_frame_view *f2, const uint32_t *node2, const uint8_t *blocked2, int max_dist,
+                         float nnratio, int check_ori, int32_t *matches12, int *nmatches);
+
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-823).  valid1 / valid2: keypoint has no map point yet
+ * (null = all); stereo flags come from the views' u_right (>= 0, null = monocular); f12: the fundamental matrix of
+ * LocalMapping::ComputeF12 (src/LocalMapping.cc:536-553) row-major; (ex, ey): epipole of camera 1 in image 2
+ * (:664-670); level_sigma2[f2->n_levels] = pKF2->mvLevelSigma2; f2->scale_factors must be set.  Candidates of the
+ * same node with Hamming distance <= TH_LOW that pass the epipole gate (:741-747) and CheckDistEpipolarLine
+ * (:140-157); smallest distance wins, the later index on ties (":735 dist>bestDist"); the reference never sets
+ * vbMatched2, so queries do not block each other.  matches12[n1] = f2 index or -1 (vMatchedPairs = the non-negative
+ * entries in index order). */
+int orbhip_search_for_triangulation(orbhip_matcher *m, const orbhip_frame_view *f1, const uint32_t *node1,
+                                    const uint8_t *valid1, const orbhip_frame_view *f2, const uint32_t *node2,
+                                    const uint8_t *valid2, const float *f12, float ex, float ey,
+                                    const float *level_sigma2, int only_stereo, int check_ori, int32_t *matches12,
+                                    int *nmatches);
 
 /* Device-resident, batched forms of the two SearchByProjection searches: `pairs` independent frame pairs,
  * asynchronous on the matcher's stream.  Train side in the extractor's output layout: d_kps [pairs][cap]

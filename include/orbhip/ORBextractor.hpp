@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../orbhip.h"
@@ -149,6 +150,39 @@ public:
         check(orbhip_search_by_projection_points(m_, &F, q.data(), qdesc, (int)q.size(), taken, assign.data(), mfNNratio,
                                                  &n), "orbhip_search_by_projection_points");
         assign.resize(F.n);
+        return n;
+    }
+
+    // int SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches)   (max_dist = TH_LOW)
+    // int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) (max_dist = TH_LOW - 1)
+    // node1/node2: FeatureVector node id per keypoint; matches12[i1] = i2 or -1
+    int SearchByBoW(const orbhip_frame_view &F1, const uint32_t *node1, const uint8_t *valid1, const orbhip_frame_view &F2,
+                    const uint32_t *node2, const uint8_t *blocked2, std::vector<int> &matches12, int max_dist = TH_LOW)
+    {
+        matches12.assign(F1.n > 0 ? F1.n : 1, -1);
+        int n = 0;
+        check(orbhip_search_by_bow(m_, &F1, node1, valid1, &F2, node2, blocked2, max_dist, mfNNratio, mbCheckOrientation,
+                                   matches12.data(), &n), "orbhip_search_by_bow");
+        matches12.resize(F1.n);
+        return n;
+    }
+
+    // int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t,size_t>> &vMatchedPairs,
+    //                            bool bOnlyStereo)
+    int SearchForTriangulation(const orbhip_frame_view &F1, const uint32_t *node1, const uint8_t *valid1,
+                               const orbhip_frame_view &F2, const uint32_t *node2, const uint8_t *valid2, const float F12[9],
+                               float ex, float ey, const float *level_sigma2,
+                               std::vector<std::pair<size_t, size_t> > &vMatchedPairs, bool bOnlyStereo)
+    {
+        std::vector<int> m12(F1.n > 0 ? F1.n : 1, -1);
+        int n = 0;
+        check(orbhip_search_for_triangulation(m_, &F1, node1, valid1, &F2, node2, valid2, F12, ex, ey, level_sigma2,
+                                              bOnlyStereo, mbCheckOrientation, m12.data(), &n),
+              "orbhip_search_for_triangulation");
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve(n);
+        for (int i = 0; i < F1.n; ++i)
+            if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
         return n;
     }
 

@@ -90,6 +90,11 @@ def lib():
                                                    C.c_void_p, C.c_void_p]
         L.oracle_search_by_projection_points.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p,
                                                          C.c_int, C.c_void_p, C.c_void_p, C.c_float]
+        L.oracle_search_by_bow.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p, C.POINTER(Frame), C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.oracle_search_for_triangulation.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p, C.POINTER(Frame),
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                     C.c_void_p, C.c_int, C.POINTER(Pyramids),
                                                     C.c_int, C.c_float, C.c_float, C.c_void_p,
@@ -259,6 +264,36 @@ def search_by_projection_points(f, queries, qdesc, taken=None, nnratio=0.8):
     n = lib().oracle_search_by_projection_points(C.byref(f), _p(q), _p(qd), len(q), _p(tk),
                                                  _p(out), nnratio)
     return n, out[:f.n].copy()
+
+
+NO_NODE = 0xFFFFFFFF
+
+
+def search_by_bow(f1, node1, valid1, f2, node2, blocked2=None, max_dist=50, nnratio=0.7, check_ori=True):
+    """ORBmatcher::SearchByBoW (both overloads); returns (nmatches, matches12[n1])."""
+    n1a = np.ascontiguousarray(node1, np.uint32)
+    n2a = np.ascontiguousarray(node2, np.uint32)
+    v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+    b2 = None if blocked2 is None else np.ascontiguousarray(blocked2, np.uint8)
+    m12 = np.zeros(max(f1.n, 1), np.int32)
+    n = lib().oracle_search_by_bow(C.byref(f1), _p(n1a), _p(v1), C.byref(f2), _p(n2a), _p(b2), int(max_dist),
+                                   nnratio, int(check_ori), _p(m12))
+    return n, m12[:f1.n].copy()
+
+
+def search_for_triangulation(f1, node1, valid1, f2, node2, valid2, F12, ex, ey, level_sigma2, only_stereo=False,
+                             check_ori=True):
+    """ORBmatcher::SearchForTriangulation; returns (nmatches, matches12[n1])."""
+    n1a = np.ascontiguousarray(node1, np.uint32)
+    n2a = np.ascontiguousarray(node2, np.uint32)
+    v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+    v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sg = np.ascontiguousarray(level_sigma2, np.float32)
+    m12 = np.zeros(max(f1.n, 1), np.int32)
+    n = lib().oracle_search_for_triangulation(C.byref(f1), _p(n1a), _p(v1), C.byref(f2), _p(n2a), _p(v2), _p(F),
+                                              float(ex), float(ey), _p(sg), int(only_stereo), int(check_ori), _p(m12))
+    return n, m12[:f1.n].copy()
 
 
 def compute_stereo_matches(keys_l, desc_l, keys_r, desc_r, levels_l, levels_r, scale, inv_scale,

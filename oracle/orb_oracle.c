@@ -1053,6 +1053,174 @@ int oracle_search_by_projection_points(const oracle_frame *f, const oracle_query
     return nmatches;
 }
 
+/* ---- vocabulary-node guided searches ------------------------------------------------------
+ * DBoW2::FeatureVector (Thirdparty/DBoW2/DBoW2/FeatureVector.h) is a std::map<NodeId, vector<feature index>>;
+ * DBoW2 fills it while walking the features in index order, so every node's list is ascending.  The vocabulary
+ * itself is outside the path: callers pass the node id of every keypoint (ORACLE_NO_NODE = not in the vector). */
+typedef struct { uint32_t node; int32_t idx; } nodeidx;
+static int nodeidx_cmp(const void *a, const void *b)
+{
+    const nodeidx *A = (const nodeidx *)a, *B = (const nodeidx *)b;
+    if (A->node != B->node) return A->node < B->node ? -1 : 1;
+    return A->idx < B->idx ? -1 : (A->idx > B->idx);
+}
+static nodeidx *feature_vector(const uint32_t *node, int n, int *count)
+{
+    nodeidx *v = (nodeidx *)malloc(sizeof(nodeidx) * (n + 1));
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (node[i] != ORACLE_NO_NODE) { v[m].node = node[i]; v[m].idx = i; ++m; }
+    qsort(v, m, sizeof(nodeidx), nodeidx_cmp);
+    *count = m;
+    return v;
+}
+static int node_end(const nodeidx *v, int m, int b)
+{
+    int e = b;
+    while (e < m && v[e].node == v[b].node) ++e;
+    return e;
+}
+
+/* SearchByBoW(KeyFrame*,Frame&,vpMapPointMatches) ORBmatcher.cc:159-288 (max_dist = TH_LOW) and
+ * SearchByBoW(KeyFrame*,KeyFrame*,vpMatches12) :522-655 (strict "<TH_LOW": max_dist = TH_LOW-1) */
+int oracle_search_by_bow(const oracle_frame *f1, const uint32_t *node1, const uint8_t *valid1,
+                         const oracle_frame *f2, const uint32_t *node2, const uint8_t *blocked2,
+                         int max_dist, float nnratio, int check_ori, int32_t *matches12)
+{
+    const int n1 = f1->n, n2 = f2->n;
+    int m1, m2, nmatches = 0;
+    nodeidx *v1 = feature_vector(node1, n1, &m1), *v2 = feature_vector(node2, n2, &m2);
+    uint8_t *matched2 = (uint8_t *)calloc(n2 + 1, 1);
+    int *hist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (n1 + 1));
+    int hs[HISTO_LENGTH] = {0};
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    int a = 0, b = 0;
+    while (a < m1 && b < m2) {
+        if (v1[a].node == v2[b].node) {
+            const int ae = node_end(v1, m1, a), be = node_end(v2, m2, b);
+            for (int i1 = a; i1 < ae; ++i1) {
+                const int idx1 = v1[i1].idx;
+                if (valid1 && !valid1[idx1]) continue;          /* !pMP || pMP->isBad() */
+                const uint8_t *d1 = f1->desc + (size_t)idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int i2 = b; i2 < be; ++i2) {
+                    const int idx2 = v2[i2].idx;
+                    if (matched2[idx2] || (blocked2 && blocked2[idx2])) continue;
+                    const int dist = oracle_descriptor_distance(d1, f2->desc + (size_t)idx2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= max_dist) {
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                        matches12[idx1] = bestIdx2;
+                        matched2[bestIdx2] = 1;
+                        if (check_ori) {
+                            int bin = rot_bin(f1->keys[idx1].angle, f2->keys[bestIdx2].angle);
+                            hist[bin * n1 + hs[bin]++] = idx1;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a = ae; b = be;
+        } else if (v1[a].node < v2[b].node) {
+            while (a < m1 && v1[a].node < v2[b].node) ++a;      /* lower_bound */
+        } else {
+            while (b < m2 && v2[b].node < v1[a].node) ++b;
+        }
+    }
+    if (check_ori) {
+        int ind1, ind2, ind3;
+        oracle_three_maxima(hs, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < hs[i]; ++j) { matches12[hist[i * n1 + j]] = -1; nmatches--; }
+    }
+    free(v1); free(v2); free(matched2); free(hist);
+    return nmatches;
+}
+
+/* CheckDistEpipolarLine, ORBmatcher.cc:140-157 (F12 row-major 3x3, float) */
+static int check_dist_epipolar_line(const oracle_kp *kp1, const oracle_kp *kp2, const float *F12,
+                                    const float *level_sigma2)
+{
+    const float a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];
+    const float b = kp1->x * F12[1] + kp1->y * F12[4] + F12[7];
+    const float c = kp1->x * F12[2] + kp1->y * F12[5] + F12[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * level_sigma2[kp2->octave];
+}
+
+/* SearchForTriangulation, ORBmatcher.cc:657-823.  (ex,ey): epipole in the second image (:664-670, computed by the
+ * caller); valid1[i] = key frame 1 has no map point at i, valid2 likewise.  vbMatched2 is never set by the reference,
+ * so there is no blocking between queries. */
+int oracle_search_for_triangulation(const oracle_frame *f1, const uint32_t *node1, const uint8_t *valid1,
+                                    const oracle_frame *f2, const uint32_t *node2, const uint8_t *valid2,
+                                    const float *F12, float ex, float ey, const float *level_sigma2,
+                                    int only_stereo, int check_ori, int32_t *matches12)
+{
+    const int n1 = f1->n, n2 = f2->n;
+    int m1, m2, nmatches = 0;
+    nodeidx *v1 = feature_vector(node1, n1, &m1), *v2 = feature_vector(node2, n2, &m2);
+    int *hist = (int *)malloc(sizeof(int) * HISTO_LENGTH * (n1 + 1));
+    int hs[HISTO_LENGTH] = {0};
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    int a = 0, b = 0;
+    while (a < m1 && b < m2) {
+        if (v1[a].node == v2[b].node) {
+            const int ae = node_end(v1, m1, a), be = node_end(v2, m2, b);
+            for (int i1 = a; i1 < ae; ++i1) {
+                const int idx1 = v1[i1].idx;
+                if (valid1 && !valid1[idx1]) continue;
+                const int bStereo1 = f1->u_right ? f1->u_right[idx1] >= 0 : 0;
+                if (only_stereo && !bStereo1) continue;
+                const oracle_kp *kp1 = &f1->keys[idx1];
+                const uint8_t *d1 = f1->desc + (size_t)idx1 * 32;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = b; i2 < be; ++i2) {
+                    const int idx2 = v2[i2].idx;
+                    if (valid2 && !valid2[idx2]) continue;
+                    const int bStereo2 = f2->u_right ? f2->u_right[idx2] >= 0 : 0;
+                    if (only_stereo && !bStereo2) continue;
+                    const int dist = oracle_descriptor_distance(d1, f2->desc + (size_t)idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const oracle_kp *kp2 = &f2->keys[idx2];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - kp2->x, distey = ey - kp2->y;
+                        if (distex * distex + distey * distey < 100 * f2->scale_factors[kp2->octave]) continue;
+                    }
+                    if (check_dist_epipolar_line(kp1, kp2, F12, level_sigma2)) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    matches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_ori) {
+                        int bin = rot_bin(kp1->angle, f2->keys[bestIdx2].angle);
+                        hist[bin * n1 + hs[bin]++] = idx1;
+                    }
+                }
+            }
+            a = ae; b = be;
+        } else if (v1[a].node < v2[b].node) {
+            while (a < m1 && v1[a].node < v2[b].node) ++a;
+        } else {
+            while (b < m2 && v2[b].node < v1[a].node) ++b;
+        }
+    }
+    if (check_ori) {
+        int ind1, ind2, ind3;
+        oracle_three_maxima(hs, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; ++i)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < hs[i]; ++j) { matches12[hist[i * n1 + j]] = -1; nmatches--; }
+    }
+    free(v1); free(v2); free(hist);
+    return nmatches;
+}
+
 /* Frame::ComputeStereoMatches, Frame.cc:466-640 */
 typedef struct { int dist, idx; } distidx;
 static int distidx_cmp(const void *a, const void *b)

@@ -149,6 +149,21 @@ int oracle_search_by_projection_points(const oracle_frame *f, const oracle_query
                                        const uint8_t *qdesc, int nq, const uint8_t *taken,
                                        int32_t *out_assign, float nnratio);
 
+/* Vocabulary-guided searches.  node1/node2: DBoW2 FeatureVector node id of every keypoint (the vocabulary lookup is
+ * outside the path), ORACLE_NO_NODE = keypoint absent from the FeatureVector.  matches12[n1] = index in f2 or -1.
+ * SearchByBoW(KeyFrame*,Frame&,..) :159-288 (max_dist=TH_LOW=50; valid1 = key frame map point exists and is good)
+ * SearchByBoW(KeyFrame*,KeyFrame*,..) :522-655 (max_dist=49; blocked2 = no good map point in key frame 2) */
+#define ORACLE_NO_NODE 0xffffffffu
+int oracle_search_by_bow(const oracle_frame *f1, const uint32_t *node1, const uint8_t *valid1,
+                         const oracle_frame *f2, const uint32_t *node2, const uint8_t *blocked2,
+                         int max_dist, float nnratio, int check_ori, int32_t *matches12);
+/* ORBmatcher::SearchForTriangulation :657-823 with CheckDistEpipolarLine :140-157; F12 row-major, (ex,ey) epipole of
+ * camera 1 in image 2, level_sigma2 = KeyFrame::mvLevelSigma2 of f2, valid* = keypoint has no map point yet */
+int oracle_search_for_triangulation(const oracle_frame *f1, const uint32_t *node1, const uint8_t *valid1,
+                                    const oracle_frame *f2, const uint32_t *node2, const uint8_t *valid2,
+                                    const float *F12, float ex, float ey, const float *level_sigma2,
+                                    int only_stereo, int check_ori, int32_t *matches12);
+
 /* Frame::ComputeStereoMatches :466-640.  pyramids: arrays of per-level
  * pointers to the level ROI (not the padded origin), steps and sizes. */
 typedef struct {

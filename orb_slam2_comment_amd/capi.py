@@ -17,6 +17,7 @@ MAX_LEVELS = 16
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+NO_NODE = 0xFFFFFFFF   # ORBHIP_NO_NODE
 QUERY_DTYPE = np.dtype([("valid", "<i4"), ("u", "<f4"), ("v", "<f4"), ("radius", "<f4"),
                         ("min_level", "<i4"), ("max_level", "<i4"), ("ur", "<f4"),
                         ("level_aux", "<i4"), ("angle", "<f4"), ("observed", "<i4")])
@@ -67,6 +68,9 @@ SYMBOLS = [
     ("orbhip_search_by_projection_keyframe", _i, [_vp, C.POINTER(FrameView), _vp, _vp, _i, _vp, _vp, _i, _i, _pi]),
     ("orbhip_search_by_projection_sim3", _i, [_vp, C.POINTER(FrameView), _vp, _vp, _i, _vp, _vp, _pi]),
     ("orbhip_search_best_in_window", _i, [_vp, C.POINTER(FrameView), _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    ("orbhip_search_by_bow", _i, [_vp, C.POINTER(FrameView), _vp, _vp, C.POINTER(FrameView), _vp, _vp, _i, _f, _i, _vp, _pi]),
+    ("orbhip_search_for_triangulation", _i, [_vp, C.POINTER(FrameView), _vp, _vp, C.POINTER(FrameView), _vp, _vp, _vp, _f,
+                                             _f, _vp, _i, _i, _vp, _pi]),
     ("orbhip_search_by_projection_frame_device", _i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp,
                                                       _vp, _i, _i, _vp, _vp]),
     ("orbhip_search_by_projection_points_device", _i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp,

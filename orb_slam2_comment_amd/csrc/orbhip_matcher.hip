@@ -184,6 +184,118 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const uint32_
     }
 }
 
+// ---- vocabulary-node candidates (SearchByBoW :159-288 / :522-655, SearchForTriangulation :657-823) ----------
+// One wavefront per query; candidates are the train keypoints filed under the same vocabulary node, in ascending
+// index (the order of a DBoW2 FeatureVector entry).  BoW: all of them, sorted by (distance, index), blocking and the
+// ratio test are left to k_resolve_par.  TRI: the epipole and epipolar-line gates are applied here and only the
+// winner (smallest distance, LAST index on ties, ":735 dist>bestDist") is kept.
+struct TriParams {
+    float f12[9];
+    float ex, ey;
+    float sigma2[ORBHIP_MAX_LEVELS], sf[ORBHIP_MAX_LEVELS];
+};
+
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_node_search(DevFrame F, const uint32_t *__restrict__ tnode,
+                                                     const uint8_t *__restrict__ tvalid,
+                                                     const orbhip_query *__restrict__ q,
+                                                     const uint8_t *__restrict__ qdesc, int nq,
+                                                     unsigned long long *__restrict__ cand, int *__restrict__ cnt,
+                                                     int stride, TriParams P)
+{
+    __shared__ unsigned long long stage[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int qi = blockIdx.x * 4 + wv;
+    if (qi >= nq) return;
+    const orbhip_query Q = q[qi];
+    const uint32_t qnode = (uint32_t)Q.level_aux;
+    uint32_t qd[8];
+    const uint32_t *qp = reinterpret_cast<const uint32_t *>(qdesc + (size_t)qi * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qd[i] = qp[i];
+    unsigned long long *out = cand + (size_t)qi * stride;
+    float la = 0.f, lb = 0.f, lc = 0.f, den = 0.f;
+    const bool stereo1 = Q.ur >= 0;
+    if (TRI) {   // epipolar line of the query in image 2, ORBmatcher.cc:143-145
+        la = __fadd_rn(__fadd_rn(__fmul_rn(Q.u, P.f12[0]), __fmul_rn(Q.v, P.f12[3])), P.f12[6]);
+        lb = __fadd_rn(__fadd_rn(__fmul_rn(Q.u, P.f12[1]), __fmul_rn(Q.v, P.f12[4])), P.f12[7]);
+        lc = __fadd_rn(__fadd_rn(__fmul_rn(Q.u, P.f12[2]), __fmul_rn(Q.v, P.f12[5])), P.f12[8]);
+        den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+    }
+    int total = 0;
+    unsigned long long best = ~0ull;
+    for (int j0 = 0; j0 < F.n; j0 += 64) {
+        const int j = j0 + lane;
+        bool ok = j < F.n && tnode[j] == qnode && (!tvalid || tvalid[j]);
+        unsigned long long key = 0;
+        if (ok) {
+            const uint32_t *tp = reinterpret_cast<const uint32_t *>(F.desc + (size_t)j * 32);
+            uint32_t td[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) td[i] = tp[i];
+            const int dist = hamming256(qd, td);
+            if (TRI) {
+                ok = dist <= TH_LOW;
+                if (ok) {
+                    const orbhip_keypoint kp = F.keys[j];
+                    const bool stereo2 = F.u_right && F.u_right[j] >= 0;
+                    if (!stereo1 && !stereo2) {   // :741-747
+                        const float dx = __fsub_rn(P.ex, kp.x), dy = __fsub_rn(P.ey, kp.y);
+                        if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.f, P.sf[kp.octave])) ok = false;
+                    }
+                    if (ok) {                     // CheckDistEpipolarLine :147-156
+                        const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, kp.x), __fmul_rn(lb, kp.y)), lc);
+                        if (den == 0) ok = false;
+                        else {
+                            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+                            ok = (double)dsqr < 3.84 * (double)P.sigma2[kp.octave];
+                        }
+                    }
+                }
+                if (ok) {
+                    const unsigned long long k = ((unsigned long long)dist << 32) | (uint32_t)(0xfffff - j);
+                    best = k < best ? k : best;
+                }
+            } else {
+                key = ((unsigned long long)dist << 32) | (uint32_t)j;
+            }
+        }
+        if (!TRI) {
+            const unsigned long long bal = __ballot(ok);
+            if (ok) {
+                const int pos = total + __popcll(bal & ((1ull << lane) - 1ull));
+                out[pos] = key;
+                if (pos < 64) stage[wv][pos] = key;
+            }
+            total += __popcll(bal);
+        }
+    }
+    if (TRI) {
+        best = wave_min_u64(best);
+        if (lane == 0) {
+            if (best == ~0ull) cnt[qi] = 0;
+            else { out[0] = (best & 0xffffffff00000000ull) | (uint32_t)(0xfffff - (int)(best & 0xfffffu)); cnt[qi] = 1; }
+        }
+        return;
+    }
+    if (total > 0 && total <= 64) {
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long v = lane < total ? stage[wv][lane] : ~0ull;
+        for (int k = 2; k <= 64; k <<= 1)
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                unsigned long long o = __shfl_xor(v, jj, 64);
+                const bool up = ((lane & k) == 0);
+                const bool lower = ((lane & jj) == 0);
+                const unsigned long long mn = o < v ? o : v, mx = o < v ? v : o;
+                v = (lower == up) ? mn : mx;
+            }
+        if (lane < total) out[lane] = v;
+        if (lane == 0) cnt[qi] = total;
+    } else if (lane == 0) {
+        cnt[qi] = -total;
+    }
+}
+
 // ---- independent best match per query (no slot blocking) ------------------------------------
 // Inner loop of ORBmatcher::Fuse (ORBmatcher.cc:893-950, :1045-1075) and of both directions of SearchBySim3
 // (:1199-1219, :1279-1299): GetFeaturesInArea window, level window, optional chi-square gate on the
@@ -453,7 +565,9 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
     if (lane == 0) *out_n = nmatches;
 }
 
-// ---- parallel resolve for the two SearchByProjection overloads (modes 0 and 1) ------------------
+// ---- parallel resolve: modes 0 / 1 (SearchByProjection overloads), 3 (SearchByBoW: best + second among unblocked
+// candidates, ratio test, every accepted match blocks its slot), 4 (SearchForTriangulation: one pre-gated candidate
+// per query, no blocking, output per query) --------------------------------------------------------------------
 // The sequential reference loop is the unique solution of
 //   choice(i) = first candidate of query i (in (distance, visiting order)) that is neither taken on entry
 //               nor chosen by an accepted, observed query j < i,
@@ -522,7 +636,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                         const unsigned long long v = list[e];
                         const int idx = (int)(v & 0xfffffu);
                         if (S.taken[idx] || S.owner[cur][idx] < i) continue;
-                        if (k1 == ~0ull) { k1 = v; if (mode == 0) break; }
+                        if (k1 == ~0ull) { k1 = v; if (mode == 0 || mode == 4) break; }
                         else { k2 = v; break; }
                     }
                 } else {       // unsorted: smallest and second smallest usable key
@@ -542,6 +656,10 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                         const int bestLevel2 = k2 == ~0ull ? -1 : (int)S.t_oct[(int)(k2 & 0xfffffu)];
                         if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) acc = false;
                     }
+                    if (acc && mode == 3) {   // SearchByBoW ratio test, ORBmatcher.cc:264 / :600
+                        const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
+                        acc = (float)bestDist < __fmul_rn(nnratio, (float)bestDist2);
+                    }
                     if (acc) newc = bestIdx;
                 }
             }
@@ -559,12 +677,13 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     for (int c = tid; c < n; c += T) assign[c] = -1;
     __syncthreads();
     int acc_local = 0;
+    const bool ori = (mode == 0 || mode >= 3) && check_ori;
     for (int i = tid; i < nq; i += T) {
         const int c = S.choice[i];
         if (c < 0) continue;
         ++acc_local;
         atomicMax(&assign[c], i);
-        if (mode == 0 && check_ori) {
+        if (ori) {
             const int bin = rot_bin(S.q_angle[i], S.t_angle[c]);
             atomicAdd(&S.hist[bin], 1);
             S.evbin[i] = (unsigned char)bin;
@@ -572,18 +691,22 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     }
     if (acc_local) atomicAdd(&S.nacc, acc_local);
     __syncthreads();
-    if (mode == 0 && check_ori) {
+    if (ori) {
         int ind1, ind2, ind3;
         three_maxima(S.hist, ind1, ind2, ind3);
         int cull = 0;
         for (int i = tid; i < nq; i += T) {
             const int b = S.evbin[i];
-            if (b != 0xff && b != ind1 && b != ind2 && b != ind3) { assign[S.choice[i]] = -1; ++cull; }
+            if (b != 0xff && b != ind1 && b != ind2 && b != ind3) {
+                if (mode == 4) S.choice[i] = -1; else assign[S.choice[i]] = -1;
+                ++cull;
+            }
         }
         if (cull) atomicAdd(&S.ncull, cull);
         __syncthreads();
     }
-    for (int c = tid; c < n; c += T) out[c] = assign[c];
+    if (mode == 4) for (int i = tid; i < nq; i += T) out[i] = S.choice[i];   // per query, no slot exclusivity
+    else for (int c = tid; c < n; c += T) out[c] = assign[c];
     if (tid == 0) *out_n = S.nacc - S.ncull;
 }
 
@@ -973,6 +1096,114 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
     return ORBHIP_OK;
 }
 
+// shared driver of SearchByBoW (tri == null) and SearchForTriangulation (tri != null)
+static int run_node_search(orbhip_matcher *m, const TriParams *tri, const orbhip_frame_view *f1, const uint32_t *node1,
+                           const uint8_t *valid1, const orbhip_frame_view *f2, const uint32_t *node2,
+                           const uint8_t *mask2, int only_stereo, int max_dist, float nnratio, int check_ori,
+                           int32_t *matches12, int *nmatches)
+{
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    const int n1 = f1->n, n2 = f2->n;
+    if (n1 > kResolveMax || n2 > kResolveMax) {
+        set_error("matcher: %d / %d keypoints exceed the LDS-resident limit %d", n1, n2, kResolveMax);
+        return ORBHIP_E_CAPACITY;
+    }
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    *nmatches = 0;
+    if (n1 == 0 || n2 == 0) return ORBHIP_OK;
+    // processing order of the reference: FeatureVector nodes ascending, feature indices ascending inside a node
+    std::vector<int> order;
+    order.reserve(n1);
+    for (int i = 0; i < n1; ++i) {
+        if (node1[i] == ORBHIP_NO_NODE || (valid1 && !valid1[i])) continue;
+        if (tri && only_stereo && !(f1->u_right && f1->u_right[i] >= 0)) continue;   // :706-708
+        order.push_back(i);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return node1[a] < node1[b]; });
+    const int nq = (int)order.size();
+    if (nq == 0) return ORBHIP_OK;
+    const size_t n = (size_t)n2;
+    Stage st;
+    int rc;
+    if ((rc = stage_begin(m, al256(n * sizeof(orbhip_keypoint)) + al256(n * 32) + 2 * al256(n * 4) + al256(n) +
+                                 al256((size_t)nq * sizeof(orbhip_query)) + al256((size_t)nq * 32), &st))) return rc;
+    DevFrame D;
+    D.n = n2; D.min_x = D.min_y = 0.f; D.inv_w = D.inv_h = 0.f;
+    D.keys = (const orbhip_keypoint *)st.put(f2->keys, n * sizeof(orbhip_keypoint));
+    D.desc = (const uint8_t *)st.put(f2->desc, n * 32);
+    D.u_right = (tri && f2->u_right) ? (const float *)st.put(f2->u_right, n * sizeof(float)) : nullptr;
+    const uint32_t *d_tnode = (const uint32_t *)st.put(node2, n * sizeof(uint32_t));
+    // BoW: mask2 = blocked slots, consumed by the resolve kernel; TRI: mask2 = candidate filter (+ bOnlyStereo :725-729)
+    const uint8_t *d_mask = nullptr;
+    if (tri) {
+        if (mask2 || only_stereo) {
+            uint8_t *hm = st.h + st.off;
+            d_mask = (const uint8_t *)st.put(nullptr, 0);
+            for (int j = 0; j < n2; ++j)
+                hm[j] = (uint8_t)((!mask2 || mask2[j]) && (!only_stereo || (f2->u_right && f2->u_right[j] >= 0)));
+            st.off += al256(n);
+        }
+    } else if (mask2) {
+        d_mask = (const uint8_t *)st.put(mask2, n);
+    }
+    orbhip_query *hq = reinterpret_cast<orbhip_query *>(st.h + st.off);
+    const orbhip_query *d_q = (const orbhip_query *)st.put(nullptr, 0);
+    st.off += al256((size_t)nq * sizeof(orbhip_query));
+    uint8_t *hqd = st.h + st.off;
+    const uint8_t *d_qdesc = (const uint8_t *)st.put(nullptr, 0);
+    st.off += al256((size_t)nq * 32);
+    for (int p = 0; p < nq; ++p) {
+        const int i = order[p];
+        orbhip_query &Q = hq[p];
+        memset(&Q, 0, sizeof(Q));
+        Q.valid = 1;
+        Q.u = f1->keys[i].x; Q.v = f1->keys[i].y;
+        Q.ur = f1->u_right ? f1->u_right[i] : -1.0f;
+        Q.level_aux = (int32_t)node1[i];
+        Q.angle = f1->keys[i].angle;
+        memcpy(hqd + (size_t)p * 32, f1->desc + (size_t)i * 32, 32);
+    }
+    if ((rc = stage_commit(m, &st))) return rc;
+    void *p;
+    const int stride = tri ? 2 : ((n2 + 1) & ~1);
+    if ((rc = scratch(m, S_CAND, (size_t)nq * stride * sizeof(unsigned long long), &p))) return rc;
+    unsigned long long *d_cand = (unsigned long long *)p;
+    if ((rc = scratch(m, S_CNT, (size_t)nq * sizeof(int), &p))) return rc;
+    int *d_cnt = (int *)p;
+    const int nout = tri ? nq : n2;
+    if ((rc = scratch(m, S_OUT, (size_t)(nout + 1) * sizeof(int), &p))) return rc;
+    int *d_out = (int *)p;
+    uint8_t *h_out;
+    if ((rc = out_buffer(m, (size_t)(nout + 1) * sizeof(int), &h_out))) return rc;
+    const Batch one = {nullptr, nullptr, 0, 0};
+    if ((rc = ensure_resolve_attr(m))) return rc;
+    if (tri) {
+        hipLaunchKernelGGL(k_node_search<true>, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_tnode, d_mask, d_q, d_qdesc,
+                           nq, d_cand, d_cnt, stride, *tri);
+        hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), sizeof(ResolveParShared), m->stream, 4, D, d_q, nq, d_cand, d_cnt,
+                           stride, (const uint8_t *)nullptr, 0.f, check_ori, d_out, d_out + nout, one, TH_LOW, 0);
+    } else {
+        TriParams none;
+        memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL(k_node_search<false>, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_tnode,
+                           (const uint8_t *)nullptr, d_q, d_qdesc, nq, d_cand, d_cnt, stride, none);
+        hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), sizeof(ResolveParShared), m->stream, 3, D, d_q, nq, d_cand, d_cnt,
+                           stride, d_mask, nnratio, check_ori, d_out, d_out + nout, one, max_dist, 1);
+    }
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)(nout + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    const int *res = reinterpret_cast<const int *>(h_out);
+    if (tri) {
+        for (int q = 0; q < nq; ++q) matches12[order[q]] = res[q];
+    } else {
+        for (int j = 0; j < n2; ++j)
+            if (res[j] >= 0) matches12[order[res[j]]] = j;
+    }
+    *nmatches = res[nout];
+    return ORBHIP_OK;
+}
+
 extern "C" {
 
 int orbhip_matcher_create(int device, orbhip_matcher **out)
@@ -1077,6 +1308,44 @@ int orbhip_search_by_projection_sim3(orbhip_matcher *m, const orbhip_frame_view 
 {
     if (!m || !kf || (nq > 0 && (!q || !qdesc)) || !assign || !nmatches || nq < 0) return ORBHIP_E_ARG;
     return run_search(m, 0, kf, q, qdesc, nullptr, nq, matched, 0.f, 0, assign, kf->n, nmatches, TH_LOW, 1, 0);
+}
+
+int orbhip_search_by_bow(orbhip_matcher *m, const orbhip_frame_view *f1, const uint32_t *node1, const uint8_t *valid1,
+                         const orbhip_frame_view *f2, const uint32_t *node2, const uint8_t *blocked2, int max_dist,
+                         float nnratio, int check_ori, int32_t *matches12, int *nmatches)
+{
+    if (!m || !f1 || !f2 || !matches12 || !nmatches || f1->n < 0 || f2->n < 0) return ORBHIP_E_ARG;
+    if ((f1->n > 0 && (!node1 || !f1->keys || !f1->desc)) || (f2->n > 0 && (!node2 || !f2->keys || !f2->desc)))
+        return ORBHIP_E_ARG;
+    return run_node_search(m, nullptr, f1, node1, valid1, f2, node2, blocked2, 0, max_dist, nnratio, check_ori, matches12,
+                           nmatches);
+}
+
+int orbhip_search_for_triangulation(orbhip_matcher *m, const orbhip_frame_view *f1, const uint32_t *node1,
+                                    const uint8_t *valid1, const orbhip_frame_view *f2, const uint32_t *node2,
+                                    const uint8_t *valid2, const float *f12, float ex, float ey,
+                                    const float *level_sigma2, int only_stereo, int check_ori, int32_t *matches12,
+                                    int *nmatches)
+{
+    if (!m || !f1 || !f2 || !f12 || !level_sigma2 || !matches12 || !nmatches || f1->n < 0 || f2->n < 0) return ORBHIP_E_ARG;
+    if ((f1->n > 0 && (!node1 || !f1->keys || !f1->desc)) || (f2->n > 0 && (!node2 || !f2->keys || !f2->desc)))
+        return ORBHIP_E_ARG;
+    if (f2->n_levels < 1 || f2->n_levels > ORBHIP_MAX_LEVELS || !f2->scale_factors) {
+        set_error("search_for_triangulation: f2 needs n_levels in [1,%d] and scale_factors", ORBHIP_MAX_LEVELS);
+        return ORBHIP_E_ARG;
+    }
+    TriParams P;
+    memset(&P, 0, sizeof(P));
+    for (int i = 0; i < 9; ++i) P.f12[i] = f12[i];
+    P.ex = ex; P.ey = ey;
+    for (int l = 0; l < f2->n_levels; ++l) { P.sigma2[l] = level_sigma2[l]; P.sf[l] = f2->scale_factors[l]; }
+    for (int j = 0; j < f2->n; ++j)
+        if (f2->keys[j].octave < 0 || f2->keys[j].octave >= f2->n_levels) {
+            set_error("search_for_triangulation: keypoint %d has octave %d outside [0,%d)", j, f2->keys[j].octave, f2->n_levels);
+            return ORBHIP_E_ARG;
+        }
+    return run_node_search(m, &P, f1, node1, valid1, f2, node2, valid2, only_stereo, TH_LOW, 0.f, check_ori, matches12,
+                           nmatches);
 }
 
 int orbhip_search_best_in_window(orbhip_matcher *m, const orbhip_frame_view *kf, const orbhip_query *q,

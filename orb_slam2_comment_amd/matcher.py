@@ -154,6 +154,45 @@ class ORBmatcher:
                                                      ptr(sig), ptr(bi), ptr(bd)), "orbhip_search_best_in_window")
         return bi[:len(q)].copy(), bd[:len(q)].copy()
 
+    # -- vocabulary-guided searches ---------------------------------------------
+    def SearchByBoW(self, F1, node1, valid1, F2, node2, blocked2=None, max_dist=50):
+        """ORBmatcher::SearchByBoW (src/ORBmatcher.cc:159-288 with max_dist=50; :522-655 with max_dist=49 and
+        blocked2 = "pKF2 has no good map point").  node1/node2: vocabulary node id per keypoint (capi.NO_NODE = absent
+        from the FeatureVector).  Returns (nmatches, matches12[n1])."""
+        v1, v2 = F1.c_view(), F2.c_view()
+        n1a = np.ascontiguousarray(node1, np.uint32)
+        n2a = np.ascontiguousarray(node2, np.uint32)
+        if len(n1a) != F1.N or len(n2a) != F2.N:
+            raise ValueError("node id arrays must have one entry per keypoint")
+        va = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+        bl = None if blocked2 is None else np.ascontiguousarray(blocked2, np.uint8)
+        m12 = np.full(max(F1.N, 1), -1, np.int32)
+        nm = C.c_int(0)
+        check(self._lib.orbhip_search_by_bow(self._h, C.byref(v1), ptr(n1a), ptr(va), C.byref(v2), ptr(n2a), ptr(bl),
+                                             int(max_dist), self.mfNNratio, int(self.mbCheckOrientation), ptr(m12),
+                                             C.byref(nm)), "orbhip_search_by_bow")
+        return nm.value, m12[:F1.N].copy()
+
+    def SearchForTriangulation(self, F1, node1, valid1, F2, node2, valid2, F12, epipole, level_sigma2, bOnlyStereo=False):
+        """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-823).  Returns (nmatches, matches12[n1]); the
+        reference's vMatchedPairs are the (i, matches12[i]) with matches12[i] >= 0."""
+        v1, v2 = F1.c_view(), F2.c_view()
+        n1a = np.ascontiguousarray(node1, np.uint32)
+        n2a = np.ascontiguousarray(node2, np.uint32)
+        if len(n1a) != F1.N or len(n2a) != F2.N:
+            raise ValueError("node id arrays must have one entry per keypoint")
+        va = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+        vb = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sg = np.ascontiguousarray(level_sigma2, np.float32)
+        m12 = np.full(max(F1.N, 1), -1, np.int32)
+        nm = C.c_int(0)
+        check(self._lib.orbhip_search_for_triangulation(self._h, C.byref(v1), ptr(n1a), ptr(va), C.byref(v2), ptr(n2a),
+                                                        ptr(vb), ptr(F), float(epipole[0]), float(epipole[1]), ptr(sg),
+                                                        int(bOnlyStereo), int(self.mbCheckOrientation), ptr(m12),
+                                                        C.byref(nm)), "orbhip_search_for_triangulation")
+        return nm.value, m12[:F1.N].copy()
+
     # -- device-resident, batched SearchByProjection ---------------------------
     def set_stream(self, stream):
         check(self._lib.orbhip_matcher_set_stream(self._h, stream), "orbhip_matcher_set_stream")

@@ -427,3 +427,128 @@ def test_matcher_golden_fixtures(env):
     mbf = float(np.float32(386.1448)); mb = float(np.float32(386.1448) / np.float32(718.856))
     n, ur, dp = pkg.ORBmatcher().ComputeStereoMatches(eL, eR, kl, dl, kr, dr, mbf, mb)
     assert n == int(g["stereo_n"]) and np.array_equal(ur, g["stereo_ur"]) and np.array_equal(dp, g["stereo_depth"])
+
+
+# ---- vocabulary-guided searches (SearchByBoW x2, SearchForTriangulation) ---------------------------------
+def _pseudo_nodes(desc, n_nodes, rng, p_absent=0.03):
+    """Stand-in for the DBoW2 FeatureVector node of each descriptor (the vocabulary file is not part of the path):
+    a coarse hash of the leading descriptor bits, so that similar descriptors mostly share a node."""
+    node = (desc[:, 0].astype(np.uint32) * 7 + (desc[:, 1].astype(np.uint32) >> 6)) % np.uint32(n_nodes)
+    node = node * np.uint32(37) + np.uint32(11)          # sparse, non-contiguous ids
+    node[rng.random(len(node)) < p_absent] = 0xFFFFFFFF
+    return node
+
+
+@pytest.mark.parametrize("W,H,nf,n_nodes", [(1241, 376, 2000, 100), (752, 480, 1000, 100), (640, 480, 3000, 7)])
+def test_search_by_bow(env, W, H, nf, n_nodes):
+    """SearchByBoW(KeyFrame*,Frame&) (Tracking::TrackReferenceKeyFrame nnratio 0.7, Relocalization 0.75) and
+    SearchByBoW(KeyFrame*,KeyFrame*) (LoopClosing 0.75): assignments identical to the oracle."""
+    pkg, M, O = env
+    rng = np.random.default_rng(W + nf)
+    ext = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    img1, img2 = synth_frame(5, W, H), synth_frame(5, W, H, shift_xy=(4, 1))
+    k1, d1 = ext(img1)
+    k2, d2 = ext(img2)
+    sf = ext.GetScaleFactors()
+    g1, o1, keep1 = _views(pkg, O, img1, k1, d1, sf)
+    g2, o2, keep2 = _views(pkg, O, img2, k2, d2, sf)
+    node1, node2 = _pseudo_nodes(d1, n_nodes, rng), _pseudo_nodes(d2, n_nodes, rng)
+    valid1 = (rng.random(len(k1)) < 0.8).astype(np.uint8)
+    blocked2 = (rng.random(len(k2)) < 0.2).astype(np.uint8)
+    total = 0
+    for nnratio, ori, max_dist, v1, b2 in ((0.7, True, 50, valid1, None), (0.75, True, 49, valid1, blocked2),
+                                           (0.9, False, 50, None, None), (0.75, False, 100, None, blocked2)):
+        m = pkg.ORBmatcher(nnratio, ori)
+        n, m12 = m.SearchByBoW(g1, node1, v1, g2, node2, b2, max_dist)
+        on, om12 = O.search_by_bow(o1, node1, v1, o2, node2, b2, max_dist, nnratio, ori)
+        assert n == on and np.array_equal(m12, om12)
+        assert n == int((m12 >= 0).sum())
+        hit = m12[m12 >= 0]
+        assert len(np.unique(hit)) == len(hit)                       # vbMatched2 / vpMapPointMatches exclusivity
+        if b2 is not None:
+            assert not b2[hit].any()
+        if v1 is not None:
+            assert v1[m12 >= 0].all()
+        assert np.array_equal(node1[m12 >= 0], node2[hit])
+        total += n
+    assert total > 100
+
+
+def test_search_by_bow_random_collisions(env):
+    """Random descriptors pressed into few nodes with many exact duplicates: long unsorted candidate lists (> 64),
+    distance ties and chains of blocked slots."""
+    pkg, M, O = env
+    rng = np.random.default_rng(77)
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    for n1, n2, n_nodes in ((900, 1100, 3), (4096, 4096, 40), (1, 1, 1), (300, 2, 2)):
+        base = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+        def noisy(n):
+            d = base[rng.integers(0, len(base), n)].copy()
+            flips = rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8) \
+                & rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            d ^= flips * (rng.random((n, 1)) < 0.7)
+            return d
+        d1, d2 = noisy(n1), noisy(n2)
+        def keys(n):
+            k = np.zeros(n, pkg.KP_DTYPE)
+            k["x"] = rng.uniform(0, 640, n); k["y"] = rng.uniform(0, 480, n)
+            k["angle"] = rng.uniform(0, 360, n).astype(np.float32); k["octave"] = rng.integers(0, 8, n)
+            return k
+        k1, k2 = keys(n1), keys(n2)
+        img = np.zeros((480, 640), np.uint8)
+        g1, o1, keep1 = _views(pkg, O, img, k1, d1, sf)
+        g2, o2, keep2 = _views(pkg, O, img, k2, d2, sf)
+        node1 = rng.integers(0, n_nodes, n1).astype(np.uint32)
+        node2 = rng.integers(0, n_nodes, n2).astype(np.uint32)
+        for nnratio, ori, max_dist in ((0.75, True, 50), (1.5, False, 100)):
+            m = pkg.ORBmatcher(nnratio, ori)
+            n, m12 = m.SearchByBoW(g1, node1, None, g2, node2, None, max_dist)
+            on, om12 = O.search_by_bow(o1, node1, None, o2, node2, None, max_dist, nnratio, ori)
+            assert n == on and np.array_equal(m12, om12)
+    # capacity error instead of silent truncation
+    big = np.zeros(4097, pkg.KP_DTYPE)
+    gb = pkg.FrameView(big, np.zeros((4097, 32), np.uint8), sf, (0, 0, 640, 480))
+    with pytest.raises(Exception):
+        pkg.ORBmatcher().SearchByBoW(gb, np.zeros(4097, np.uint32), None, gb, np.zeros(4097, np.uint32))
+
+
+@pytest.mark.parametrize("W,H,nf,only_stereo", [(1241, 376, 2000, False), (752, 480, 1500, False), (1241, 376, 2000, True)])
+def test_search_for_triangulation(env, W, H, nf, only_stereo):
+    """LocalMapping::CreateNewMapPoints -> SearchForTriangulation(pKF1, pKF2, F12, pairs, false), nnratio 0.6."""
+    pkg, M, O = env
+    rng = np.random.default_rng(nf + W)
+    ext = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    img1, img2 = synth_frame(9, W, H), synth_frame(9, W, H, shift_xy=(6, 0))
+    k1, d1 = ext(img1)
+    k2, d2 = ext(img2)
+    sf = ext.GetScaleFactors()
+    sigma2 = ext.GetScaleSigmaSquares()
+    ur1 = np.where(rng.random(len(k1)) < 0.5, k1["x"] - 10, -1).astype(np.float32)
+    ur2 = np.where(rng.random(len(k2)) < 0.5, k2["x"] - 10, -1).astype(np.float32)
+    g1, o1, keep1 = _views(pkg, O, img1, k1, d1, sf, ur1)
+    g2, o2, keep2 = _views(pkg, O, img2, k2, d2, sf, ur2)
+    node1, node2 = _pseudo_nodes(d1, 100, rng), _pseudo_nodes(d2, 100, rng)
+    valid1 = (rng.random(len(k1)) < 0.7).astype(np.uint8)
+    valid2 = (rng.random(len(k2)) < 0.7).astype(np.uint8)
+    # sideways motion: epipolar line of (x1, y1) is the row y2 = y1; epipole placed inside the image so that the
+    # "too close to the epipole" gate (:741-747) rejects part of the monocular candidates
+    F_rows = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    th = np.float32(0.01)
+    F_tilt = (F_rows + np.array([[0, th, 0], [-th, 0, 0], [0, 0, 0]], np.float32) * np.float32(0.01)).astype(np.float32)
+    total = 0
+    for F12, epi, ori in ((F_rows, (W / 2.0, H / 2.0), True), (F_tilt, (W / 3.0, H / 1.5), False),
+                          (np.zeros((3, 3), np.float32), (0.0, 0.0), True)):
+        m = pkg.ORBmatcher(0.6, ori)
+        n, m12 = m.SearchForTriangulation(g1, node1, valid1, g2, node2, valid2, F12, epi, sigma2, only_stereo)
+        on, om12 = O.search_for_triangulation(o1, node1, valid1, o2, node2, valid2, F12, epi[0], epi[1], sigma2,
+                                              only_stereo, ori)
+        assert n == on and np.array_equal(m12, om12)
+        assert n == int((m12 >= 0).sum())
+        assert valid1[m12 >= 0].all() and valid2[m12[m12 >= 0]].all()
+        if only_stereo:
+            assert (ur1[m12 >= 0] >= 0).all() and (ur2[m12[m12 >= 0]] >= 0).all()
+        total += n
+    assert total > (20 if only_stereo else 100)
+    n0, m0 = pkg.ORBmatcher(0.6, True).SearchForTriangulation(g1, node1, None, g2, node2, None, np.zeros(9, np.float32),
+                                                              (0, 0), sigma2)
+    assert n0 == 0 and (m0 == -1).all()            # den == 0 -> CheckDistEpipolarLine false (:152-153)

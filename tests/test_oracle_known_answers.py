@@ -295,3 +295,70 @@ def test_oracle_reproduces_committed_golden_vectors(oracle):
     prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
     n, m12, _ = oracle.search_for_initialization(f1, f2, prev, 100, 0.9, True)
     assert n == int(m["init_n"]) and np.array_equal(m12, m["init_m12"])
+
+
+def _mini_frame(oracle, xy, desc, angles=None, octaves=None, u_right=None):
+    keep = []
+    k = np.zeros(len(xy), oracle.KP_DTYPE)
+    k["x"], k["y"] = np.asarray(xy, np.float32).reshape(-1, 2).T
+    k["angle"] = 0 if angles is None else angles
+    k["octave"] = 0 if octaves is None else octaves
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    f = oracle.make_frame(k, np.asarray(desc, np.uint8).reshape(-1, 32), u_right, (0, 0, 640, 480), sf, keep)
+    return f, keep
+
+
+def test_search_by_bow_hand_worked(oracle):
+    """Worked by hand from ORBmatcher.cc:205-262: best/second among the node's unmatched features, ratio test,
+    matched features are skipped by later queries, different nodes never meet."""
+    z = np.zeros(32, np.uint8)
+    q1 = z.copy(); q1[0] = 0b1                       # one bit
+    e1 = z.copy(); e1[0] = 0b11                      # two bits: distance 2 to q0, 1 to q1
+    e2 = z.copy(); e2[8:13] = 0xFF                   # 40 bits
+    f1, k1 = _mini_frame(oracle, [(10, 10), (20, 20), (30, 30)], [z, q1, e2])
+    f2, k2 = _mini_frame(oracle, [(11, 10), (21, 20), (31, 30)], [z, e1, e2])
+    n, m12 = oracle.search_by_bow(f1, [5, 5, 6], None, f2, [5, 5, 5], None, 50, 0.7, False)
+    # q0: best e0 (0) second e1 (2) -> 0 < 1.4 ok.  q1: e0 gone; best e1 (1), second e2 (41) ok.  q2 sits in node 6.
+    assert n == 2 and m12.tolist() == [0, 1, -1]
+    # same node for q2: its twin e2 is still free -> distance 0, no second candidate (256) -> accepted
+    n, m12 = oracle.search_by_bow(f1, [5, 5, 5], None, f2, [5, 5, 5], None, 50, 0.7, False)
+    assert n == 3 and m12.tolist() == [0, 1, 2]
+    # two equally good candidates fail the ratio test (d < 0.7*d is false), and 0 < 0.7*0 is false too
+    f2b, k2b = _mini_frame(oracle, [(1, 1), (2, 2)], [e1, e1])
+    n, m12 = oracle.search_by_bow(f1, [5, 0xFFFFFFFF, 0xFFFFFFFF], None, f2b, [5, 5], None, 50, 0.7, False)
+    assert n == 0 and m12.tolist() == [-1, -1, -1]
+    # threshold: distance 41 > TH_LOW-style bound 40 rejected, bound 41 accepted; blocked2 removes a candidate
+    f1c, k1c = _mini_frame(oracle, [(0, 0)], [q1])
+    f2c, k2c = _mini_frame(oracle, [(0, 0), (5, 5)], [e2, z])
+    assert oracle.search_by_bow(f1c, [1], None, f2c, [1, 1], [0, 1], 40, 0.9, False)[0] == 0
+    n, m12 = oracle.search_by_bow(f1c, [1], None, f2c, [1, 1], [0, 1], 41, 0.9, False)
+    assert n == 1 and m12.tolist() == [0]
+    n, m12 = oracle.search_by_bow(f1c, [1], None, f2c, [1, 1], None, 50, 0.9, False)
+    assert n == 1 and m12.tolist() == [1]           # best 1 (z), second 41: 1 < 36.9
+    assert oracle.search_by_bow(f1c, [1], [0], f2c, [1, 1], None, 50, 0.9, False)[0] == 0   # no map point in KF1
+
+
+def test_search_for_triangulation_hand_worked(oracle):
+    """ORBmatcher.cc:712-757: equal distances -> the LATER index wins (":735 dist>bestDist"); the epipole gate and the
+    epipolar-line test remove candidates; stereo keypoints skip the epipole gate."""
+    z = np.zeros(32, np.uint8)
+    F_rows = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)     # line of (x1,y1): y2 = y1
+    sigma2 = (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2
+    f1, k1 = _mini_frame(oracle, [(100, 50)], [z])
+    f2, k2 = _mini_frame(oracle, [(90, 50), (80, 50), (70, 53)], [z, z, z])
+    args = ([3], None, f2, [3, 3, 3], None, F_rows)
+    n, m12 = oracle.search_for_triangulation(f1, *args, 1000.0, 1000.0, sigma2, False, False)
+    assert n == 1 and m12.tolist() == [1]            # idx 2 is 3 px off the line: 9 > 3.84
+    n, m12 = oracle.search_for_triangulation(f1, *args, 80.0, 55.0, sigma2, False, False)
+    assert m12.tolist() == [0]                       # idx 1 is 5 px from the epipole: 25 < 100*1.0
+    f2s, k2s = _mini_frame(oracle, [(90, 50), (80, 50), (70, 53)], [z, z, z], u_right=[-1, 70, -1])
+    n, m12 = oracle.search_for_triangulation(f1, [3], None, f2s, [3, 3, 3], None, F_rows, 80.0, 55.0, sigma2, False, False)
+    assert m12.tolist() == [1]                       # stereo candidate is exempt from the epipole gate
+    n, m12 = oracle.search_for_triangulation(f1, [3], None, f2s, [3, 3, 3], None, F_rows, 80.0, 55.0, sigma2, True, False)
+    assert n == 0                                    # bOnlyStereo: the query itself is monocular
+    f2o, k2o = _mini_frame(oracle, [(70, 53)], [z], octaves=[5])
+    n, m12 = oracle.search_for_triangulation(f1, [3], None, f2o, [3], None, F_rows, 1000.0, 1000.0, sigma2, False, False)
+    assert m12.tolist() == [0]                       # 9 < 3.84*1.2^10 = 23.8 at level 5
+    far = z.copy(); far[:7] = 0xFF                   # 56 bits > TH_LOW
+    f2f, k2f = _mini_frame(oracle, [(90, 50)], [far])
+    assert oracle.search_for_triangulation(f1, [3], None, f2f, [3], None, F_rows, 1000.0, 1000.0, sigma2, False, False)[0] == 0
