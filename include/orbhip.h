@@ -25,6 +25,8 @@
  *                                     (src/ORBmatcher.cc:290-403, loop closing)
  *   orbhip_search_best_in_window      inner search of ORBmatcher::Fuse x2 (src/ORBmatcher.cc:825-1100) and of both
  *                                     directions of SearchBySim3 (:1102-1326)
+ *   orbhip_vocabulary_*               ORBVocabulary (DBoW2::TemplatedVocabulary<FORB>) loadFromTextFile + transform,
+ *                                     i.e. Frame::ComputeBoW (src/Frame.cc:395-402)
  *   orbhip_search_by_bow              ORBmatcher::SearchByBoW(KeyFrame*,Frame&,..) (src/ORBmatcher.cc:159-288) and
  *                                     SearchByBoW(KeyFrame*,KeyFrame*,..) (:522-655); vocabulary node ids are inputs
  *   orbhip_search_for_triangulation   ORBmatcher::SearchForTriangulation (:657-823) incl. CheckDistEpipolarLine (:140-157)
@@ -220,7 +222,7 @@ int orbhip_search_best_in_window(orbhip_matcher *m, const orbhip_frame_view *kf,
  * best <= max_dist (TH_LOW = 50 for the Frame overload :262, 49 for the key-frame overload's strict "<" :598) and
  * (float)best < nnratio*(float)second; rotation-histogram cull when check_ori.  matches12[n1] = f2 index or -1
  * (the Frame overload's vpMapPointMatches[idx2] = map point of idx1 is the inverse of this 1:1 map).
- * n1, n2 <= 4096 (ORBHIP_E_CAPACITY otherwise). */
+ * No size limit beyond memory (one wavefront per common node). */
 #define ORBHIP_NO_NODE 0xffffffffu
 int orbhip_search_by_bow(orbhip_matcher *m, const orbhip_frame_view *f1, const uint32_t *node1, const uint8_t *valid1,
                          const orbhip_frame_view *f2, const uint32_t *node2, const uint8_t *blocked2, int max_dist,
@@ -233,12 +235,51 @@ int orbhip_search_by_bow(orbhip_matcher *m, const orbhip_frame_view *f1, const u
  * same node with Hamming distance <= TH_LOW that pass the epipole gate (:741-747) and CheckDistEpipolarLine
  * (:140-157); smallest distance wins, the later index on ties (":735 dist>bestDist"); the reference never sets
  * vbMatched2, so queries do not block each other.  matches12[n1] = f2 index or -1 (vMatchedPairs = the non-negative
- * entries in index order). */
+ * entries in index order).  n1, n2 <= 4096 (ORBHIP_E_CAPACITY otherwise). */
 int orbhip_search_for_triangulation(orbhip_matcher *m, const orbhip_frame_view *f1, const uint32_t *node1,
                                     const uint8_t *valid1, const orbhip_frame_view *f2, const uint32_t *node2,
                                     const uint8_t *valid2, const float *f12, float ex, float ey,
                                     const float *level_sigma2, int only_stereo, int check_ori, int32_t *matches12,
                                     int *nmatches);
+
+/* ---- DBoW2 vocabulary: ORBVocabulary::loadFromTextFile + transform ---------------------------------------------
+ * Replaces, for Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:395-402, src/KeyFrame.cc ComputeBoW), the
+ * calls mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4) into
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1199 (+ :1218-1262 per feature, BowVector.cpp:36-88,
+ * FeatureVector.cpp:31-46, FORB.cpp:81-101).  scoring / weighting use DBoW2's enum values (BowVector.h:36-53:
+ * scoring 0 L1_NORM .. 5 DOT_PRODUCT; weighting 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; ORBvoc.txt is "10 6 0 0"). */
+typedef struct orbhip_vocabulary orbhip_vocabulary;
+
+/* Text format of TemplatedVocabulary::loadFromTextFile (:1338-1424): first line "k L scoring weighting", then one
+ * line per node "parent isLeaf d0 .. d31 weight" (node ids in file order from 1, root = 0, word ids in order of the
+ * leaf lines).  Blank lines are skipped (the reference turns the empty line after the final newline into an extra
+ * root child with an uninitialised descriptor). */
+int orbhip_vocabulary_load_text(const char *path, int device, orbhip_vocabulary **out);
+/* The same tree from arrays: entry i describes node i+1; parent[i] in [0, i]. */
+int orbhip_vocabulary_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t *parent,
+                             const uint8_t *is_leaf, const uint8_t *desc, const double *weight, int device,
+                             orbhip_vocabulary **out);
+void orbhip_vocabulary_destroy(orbhip_vocabulary *v);
+/* any output pointer may be null; n_nodes counts the root */
+int orbhip_vocabulary_info(const orbhip_vocabulary *v, int *k, int *L, int *scoring, int *weighting, int *n_nodes,
+                           int *n_words);
+int orbhip_vocabulary_set_stream(orbhip_vocabulary *v, void *hip_stream);   /* null = the handle's own stream */
+int orbhip_vocabulary_sync(orbhip_vocabulary *v);
+
+/* transform(features, BowVector, FeatureVector, levelsup) for n descriptors (n x 32 bytes, n <= 8192).
+ * Per feature (each array n entries, nullable): word_id, word_weight, node_id = the FeatureVector node (ancestor at
+ * level L - levelsup, 0 = root when levelsup >= L) or ORBHIP_NO_NODE when the word is stopped (weight <= 0); this is
+ * the node1 / node2 input of orbhip_search_by_bow.  BowVector: bow_ids ascending with bow_vals (capacity n each,
+ * nullable), *n_bow entries; values are accumulated and normalised in the reference's order, so they are
+ * bit-identical doubles. */
+int orbhip_vocabulary_transform(orbhip_vocabulary *v, const uint8_t *desc, int n, int levelsup, uint32_t *word_id,
+                                double *word_weight, uint32_t *node_id, uint32_t *bow_ids, double *bow_vals, int *n_bow);
+/* Device-resident, batched: descriptors in the extractor's output layout d_desc [frames][cap][32] with d_n [frames]
+ * int32 counts; outputs d_word_id / d_node_id / d_bow_ids [frames][cap] uint32, d_word_weight / d_bow_vals
+ * [frames][cap] double, d_n_bow [frames] int32.  Asynchronous on the handle's stream.  cap <= 8192. */
+int orbhip_vocabulary_transform_device(orbhip_vocabulary *v, int frames, const void *d_desc, const void *d_n, int cap,
+                                       int levelsup, void *d_word_id, void *d_word_weight, void *d_node_id,
+                                       void *d_bow_ids, void *d_bow_vals, void *d_n_bow);
 
 /* Device-resident, batched forms of the two SearchByProjection searches: `pairs` independent frame pairs,
  * asynchronous on the matcher's stream.  Train side in the extractor's output layout: d_kps [pairs][cap]

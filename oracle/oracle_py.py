@@ -95,6 +95,12 @@ def lib():
         L.oracle_search_for_triangulation.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p, C.POINTER(Frame),
                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                                       C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_vocabulary_load_text.restype = C.c_void_p
+        L.oracle_vocabulary_load_text.argtypes = [C.c_char_p]
+        L.oracle_vocabulary_destroy.argtypes = [C.c_void_p]
+        L.oracle_vocabulary_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 6
+        L.oracle_vocabulary_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                     C.c_void_p, C.c_int, C.POINTER(Pyramids),
                                                     C.c_int, C.c_float, C.c_float, C.c_void_p,
@@ -267,6 +273,39 @@ def search_by_projection_points(f, queries, qdesc, taken=None, nnratio=0.8):
 
 
 NO_NODE = 0xFFFFFFFF
+
+
+class OracleVocabulary:
+    """DBoW2 text vocabulary + transform (TemplatedVocabulary.h:1338-1424, :1127-1262), CPU restatement."""
+
+    def __init__(self, path):
+        self._h = lib().oracle_vocabulary_load_text(str(path).encode())
+        if not self._h:
+            raise ValueError("not a DBoW2 text vocabulary: %s" % path)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_vocabulary_destroy(self._h)
+            self._h = None
+
+    def info(self):
+        v = [C.c_int(0) for _ in range(6)]
+        lib().oracle_vocabulary_info(self._h, *[C.byref(x) for x in v])
+        return dict(zip(("k", "L", "scoring", "weighting", "n_nodes", "n_words"), [x.value for x in v]))
+
+    def transform(self, descriptors, levelsup=4):
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        word = np.zeros(max(n, 1), np.uint32)
+        wgt = np.zeros(max(n, 1), np.float64)
+        node = np.zeros(max(n, 1), np.uint32)
+        bid = np.zeros(max(n, 1), np.uint32)
+        bval = np.zeros(max(n, 1), np.float64)
+        nb = lib().oracle_vocabulary_transform(self._h, _p(d), n, int(levelsup), _p(word), _p(wgt), _p(node), _p(bid),
+                                               _p(bval))
+        return {"word_id": word[:n].copy(), "word_weight": wgt[:n].copy(), "node_id": node[:n].copy(),
+                "bow_ids": bid[:nb].copy(), "bow_vals": bval[:nb].copy()}
+
 
 
 def search_by_bow(f1, node1, valid1, f2, node2, blocked2=None, max_dist=50, nnratio=0.7, check_ori=True):

@@ -9,6 +9,7 @@
 #include <float.h>
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1333,4 +1334,180 @@ int oracle_compute_stereo_matches(const oracle_kp *kl, const uint8_t *dl, int N,
     for (int i = 0; i < nRows; ++i) free(rows[i]);
     free(rows); free(rowCnt); free(vDistIdx);
     return nm;
+}
+
+/* ---- DBoW2 vocabulary: loadFromTextFile + transform --------------------------------------------------------
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424 (text format), :1127-1199 (transform of a feature set),
+ * :1218-1262 (descent of one feature), BowVector.cpp:36-88 (addWeight / addIfNotExist / normalize),
+ * FeatureVector.cpp:31-46, FORB.cpp:81-101 (Hamming distance).  Deviations, both where the reference's behaviour is
+ * undefined: (1) blank lines are skipped -- the reference's `while(!f.eof())` loop turns the empty line after the
+ * last '\n' into one more child of the root whose descriptor is uninitialised memory; (2) when a leaf is reached
+ * above level L-levelsup the reference leaves *nid unset; here the leaf's own id is reported. */
+typedef struct {
+    int parent, is_leaf_flag, nchild, cap;
+    int *children;
+    uint8_t desc[32];
+    double weight;
+    uint32_t word_id;
+} voc_node;
+struct oracle_vocabulary {
+    int k, L, scoring, weighting, n_nodes, n_words;
+    voc_node *nodes;
+};
+
+void oracle_vocabulary_destroy(oracle_vocabulary *v)
+{
+    if (!v) return;
+    for (int i = 0; i < v->n_nodes; ++i) free(v->nodes[i].children);
+    free(v->nodes);
+    free(v);
+}
+
+static int voc_push_node(oracle_vocabulary *v, int *cap)
+{
+    if (v->n_nodes == *cap) {
+        *cap = *cap * 2 + 16;
+        v->nodes = (voc_node *)realloc(v->nodes, sizeof(voc_node) * (size_t)*cap);
+    }
+    memset(&v->nodes[v->n_nodes], 0, sizeof(voc_node));
+    return v->n_nodes++;
+}
+
+oracle_vocabulary *oracle_vocabulary_load_text(const char *path)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return NULL;
+    oracle_vocabulary *v = (oracle_vocabulary *)calloc(1, sizeof(*v));
+    size_t lcap = 1 << 12;
+    char *line = (char *)malloc(lcap);
+    int cap = 0, ok = 0;
+    if (fgets(line, (int)lcap, f)) {
+        int n1 = -1, n2 = -1;
+        v->k = -1; v->L = -1;
+        if (sscanf(line, "%d %d %d %d", &v->k, &v->L, &n1, &n2) == 4 &&
+            !(v->k < 0 || v->k > 20 || v->L < 1 || v->L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3)) {
+            v->scoring = n1; v->weighting = n2;
+            ok = 1;
+        }
+    }
+    if (ok) {
+        voc_push_node(v, &cap); /* root, id 0 */
+        while (fgets(line, (int)lcap, f)) {
+            char *p = line, *e;
+            while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') ++p;
+            if (!*p) continue;
+            const int nid = voc_push_node(v, &cap);
+            voc_node *nd = &v->nodes[nid];
+            const long pid = strtol(p, &e, 10);
+            if (e == p || pid < 0 || pid >= nid) { ok = 0; break; }
+            p = e;
+            nd->parent = (int)pid;
+            voc_node *par = &v->nodes[pid];
+            if (par->nchild == par->cap) {
+                par->cap = par->cap * 2 + 4;
+                par->children = (int *)realloc(par->children, sizeof(int) * (size_t)par->cap);
+            }
+            par->children[par->nchild++] = nid;
+            nd->is_leaf_flag = (int)strtol(p, &e, 10);
+            if (e == p) { ok = 0; break; }
+            p = e;
+            for (int i = 0; i < 32; ++i) {
+                const long b = strtol(p, &e, 10);
+                if (e == p) { ok = 0; break; }
+                nd->desc[i] = (uint8_t)b;
+                p = e;
+            }
+            if (!ok) break;
+            nd->weight = strtod(p, &e);
+            if (e == p) { ok = 0; break; }
+            if (nd->is_leaf_flag > 0) nd->word_id = (uint32_t)v->n_words++;
+        }
+    }
+    free(line);
+    fclose(f);
+    if (!ok) { oracle_vocabulary_destroy(v); return NULL; }
+    return v;
+}
+
+void oracle_vocabulary_info(const oracle_vocabulary *v, int *k, int *L, int *scoring, int *weighting, int *n_nodes,
+                            int *n_words)
+{
+    *k = v->k; *L = v->L; *scoring = v->scoring; *weighting = v->weighting;
+    *n_nodes = v->n_nodes; *n_words = v->n_words;
+}
+
+/* transform(feature, word_id, weight, nid, levelsup), TemplatedVocabulary.h:1218-1262 */
+static void voc_transform_one(const oracle_vocabulary *v, const uint8_t *feature, int levelsup, uint32_t *word_id,
+                              double *weight, uint32_t *nid)
+{
+    const int nid_level = v->L - levelsup;
+    int nid_set = 0;
+    if (nid_level <= 0) { *nid = 0; nid_set = 1; }
+    int final_id = 0, current_level = 0;
+    do {
+        ++current_level;
+        const voc_node *nd = &v->nodes[final_id];
+        final_id = nd->children[0];
+        double best_d = oracle_descriptor_distance(feature, v->nodes[final_id].desc);
+        for (int c = 1; c < nd->nchild; ++c) {
+            const int id = nd->children[c];
+            const double d = oracle_descriptor_distance(feature, v->nodes[id].desc);
+            if (d < best_d) { best_d = d; final_id = id; }
+        }
+        if (current_level == nid_level) { *nid = (uint32_t)final_id; nid_set = 1; }
+    } while (v->nodes[final_id].nchild != 0);
+    if (!nid_set) *nid = (uint32_t)final_id;
+    *word_id = v->nodes[final_id].word_id;
+    *weight = v->nodes[final_id].weight;
+}
+
+typedef struct { uint32_t id; int idx; } wordidx;
+static int wordidx_cmp(const void *a, const void *b)
+{
+    const wordidx *A = (const wordidx *)a, *B = (const wordidx *)b;
+    if (A->id != B->id) return A->id < B->id ? -1 : 1;
+    return A->idx < B->idx ? -1 : (A->idx > B->idx);
+}
+
+/* transform(features, BowVector, FeatureVector, levelsup), :1127-1199.  word_id/weight/node_id: per feature
+ * (node_id = ORACLE_NO_NODE for stopped words, w <= 0); bow_ids/bow_vals: the BowVector in map order. */
+int oracle_vocabulary_transform(const oracle_vocabulary *v, const uint8_t *desc, int n, int levelsup,
+                                uint32_t *word_id, double *weight, uint32_t *node_id, uint32_t *bow_ids,
+                                double *bow_vals)
+{
+    for (int i = 0; i < n; ++i) { word_id[i] = 0; weight[i] = 0; node_id[i] = ORACLE_NO_NODE; }
+    if (v->n_words == 0 || n == 0) return 0;   /* empty() */
+    const int must = v->scoring != 5;           /* DotProductScoring: no normalisation */
+    const int l2 = v->scoring == 1;
+    wordidx *w = (wordidx *)malloc(sizeof(wordidx) * (size_t)(n + 1));
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        uint32_t nid;
+        voc_transform_one(v, desc + (size_t)i * 32, levelsup, &word_id[i], &weight[i], &nid);
+        if (weight[i] > 0) { node_id[i] = nid; w[m].id = word_id[i]; w[m].idx = i; ++m; }
+    }
+    /* std::map<WordId,WordValue> filled in feature order == stable grouping by word id */
+    qsort(w, m, sizeof(wordidx), wordidx_cmp);
+    int nb = 0;
+    const int accumulate = v->weighting == 0 || v->weighting == 1;   /* TF_IDF, TF: addWeight; IDF, BINARY: addIfNotExist */
+    for (int a = 0; a < m;) {
+        int b = a;
+        double val = weight[w[a].idx];
+        for (b = a + 1; b < m && w[b].id == w[a].id; ++b)
+            if (accumulate) val += weight[w[b].idx];
+        bow_ids[nb] = w[a].id; bow_vals[nb] = val; ++nb;
+        a = b;
+    }
+    free(w);
+    if (accumulate && nb > 0 && !must) {
+        const double nd = nb;
+        for (int i = 0; i < nb; ++i) bow_vals[i] /= nd;
+    }
+    if (must) {   /* BowVector::normalize */
+        double norm = 0.0;
+        if (!l2) for (int i = 0; i < nb; ++i) norm += fabs(bow_vals[i]);
+        else { for (int i = 0; i < nb; ++i) norm += bow_vals[i] * bow_vals[i]; norm = sqrt(norm); }
+        if (norm > 0.0) for (int i = 0; i < nb; ++i) bow_vals[i] /= norm;
+    }
+    return nb;
 }

@@ -164,6 +164,19 @@ int oracle_search_for_triangulation(const oracle_frame *f1, const uint32_t *node
                                     const float *F12, float ex, float ey, const float *level_sigma2,
                                     int only_stereo, int check_ori, int32_t *matches12);
 
+/* DBoW2 vocabulary (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h): loadFromTextFile :1338-1424 and
+ * transform(features, BowVector, FeatureVector, levelsup) :1127-1199 as called by Frame::ComputeBoW (Frame.cc:395-402,
+ * levelsup = 4).  Returns the BowVector size; per-feature word id / weight / FeatureVector node id, and the
+ * BowVector (ids ascending).  All output arrays have n entries. */
+typedef struct oracle_vocabulary oracle_vocabulary;
+oracle_vocabulary *oracle_vocabulary_load_text(const char *path);
+void oracle_vocabulary_destroy(oracle_vocabulary *v);
+void oracle_vocabulary_info(const oracle_vocabulary *v, int *k, int *L, int *scoring, int *weighting, int *n_nodes,
+                            int *n_words);
+int oracle_vocabulary_transform(const oracle_vocabulary *v, const uint8_t *desc, int n, int levelsup,
+                                uint32_t *word_id, double *weight, uint32_t *node_id, uint32_t *bow_ids,
+                                double *bow_vals);
+
 /* Frame::ComputeStereoMatches :466-640.  pyramids: arrays of per-level
  * pointers to the level ROI (not the padded origin), steps and sizes. */
 typedef struct {

@@ -71,6 +71,14 @@ SYMBOLS = [
     ("orbhip_search_by_bow", _i, [_vp, C.POINTER(FrameView), _vp, _vp, C.POINTER(FrameView), _vp, _vp, _i, _f, _i, _vp, _pi]),
     ("orbhip_search_for_triangulation", _i, [_vp, C.POINTER(FrameView), _vp, _vp, C.POINTER(FrameView), _vp, _vp, _vp, _f,
                                              _f, _vp, _i, _i, _vp, _pi]),
+    ("orbhip_vocabulary_load_text", _i, [C.c_char_p, _i, C.POINTER(_vp)]),
+    ("orbhip_vocabulary_create", _i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp)]),
+    ("orbhip_vocabulary_destroy", None, [_vp]),
+    ("orbhip_vocabulary_info", _i, [_vp, _pi, _pi, _pi, _pi, _pi, _pi]),
+    ("orbhip_vocabulary_set_stream", _i, [_vp, _vp]),
+    ("orbhip_vocabulary_sync", _i, [_vp]),
+    ("orbhip_vocabulary_transform", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _pi]),
+    ("orbhip_vocabulary_transform_device", _i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("orbhip_search_by_projection_frame_device", _i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp,
                                                       _vp, _i, _i, _vp, _vp]),
     ("orbhip_search_by_projection_points_device", _i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp,

@@ -184,26 +184,131 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const uint32_
     }
 }
 
-// ---- vocabulary-node candidates (SearchByBoW :159-288 / :522-655, SearchForTriangulation :657-823) ----------
-// One wavefront per query; candidates are the train keypoints filed under the same vocabulary node, in ascending
-// index (the order of a DBoW2 FeatureVector entry).  BoW: all of them, sorted by (distance, index), blocking and the
-// ratio test are left to k_resolve_par.  TRI: the epipole and epipolar-line gates are applied here and only the
-// winner (smallest distance, LAST index on ties, ":735 dist>bestDist") is kept.
+// ---- vocabulary-node guided searches (SearchByBoW :159-288 / :522-655, SearchForTriangulation :657-823) -------
+// Both visit the key frame's features in FeatureVector order (node id, then feature index) and only compare
+// features filed under the same vocabulary node, in ascending index.
+//
+// SearchByBoW: matches of one node never interact with another node (a feature sits in exactly one node), so one
+// wavefront owns one common node and replays its queries in order; lanes hold the node's candidates (the first 64
+// in registers), the "already matched" flags live in slot space and each slot is only ever touched by the lane
+// that owns it.  Best / second-best = two wave minima of (distance << 32 | slot).
+struct NodeGroup { int q_begin, q_end, t_begin, t_end; };
+__device__ __forceinline__ int rot_bin(float a1, float a2);
+__device__ __forceinline__ void three_maxima(const int *h, int &ind1, int &ind2, int &ind3);
+
+__global__ __launch_bounds__(256) void k_bow_groups(const NodeGroup *__restrict__ groups, int ngroups,
+                                                    const uint8_t *__restrict__ qdesc, const float *__restrict__ qangle,
+                                                    const uint32_t *__restrict__ t_order, const uint8_t *__restrict__ tdesc,
+                                                    const orbhip_keypoint *__restrict__ tkeys,
+                                                    uint8_t *__restrict__ matched, int max_dist, float nnratio,
+                                                    int check_ori, int *__restrict__ match_out,
+                                                    uint8_t *__restrict__ bin_out, int *__restrict__ hist)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= ngroups) return;
+    const NodeGroup G = groups[g];
+    const int tc = G.t_end - G.t_begin;
+    // first chunk of candidates in registers
+    uint32_t td0[8];
+    const bool have0 = lane < tc;
+    {
+        const uint32_t *tp = reinterpret_cast<const uint32_t *>(tdesc + (size_t)(have0 ? t_order[G.t_begin + lane] : 0) * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) td0[i] = have0 ? tp[i] : 0u;
+    }
+    bool used0 = have0 ? matched[G.t_begin + lane] != 0 : true;
+    uint32_t qnext[8];
+    {
+        const uint32_t *qp = reinterpret_cast<const uint32_t *>(qdesc + (size_t)G.q_begin * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qnext[i] = qp[i];
+    }
+    for (int qi = G.q_begin; qi < G.q_end; ++qi) {
+        uint32_t qd[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qd[i] = qnext[i];
+        if (qi + 1 < G.q_end) {   // the next query's descriptor travels while this one is resolved
+            const uint32_t *qp = reinterpret_cast<const uint32_t *>(qdesc + (size_t)(qi + 1) * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qnext[i] = qp[i];
+        }
+        unsigned long long k1 = ~0ull, k2 = ~0ull;
+        if (!used0) k1 = ((unsigned long long)hamming256(qd, td0) << 32) | (unsigned)(G.t_begin + lane);
+        for (int c = G.t_begin + 64 + lane; c < G.t_end; c += 64) {
+            if (matched[c]) continue;
+            const uint32_t *tp = reinterpret_cast<const uint32_t *>(tdesc + (size_t)t_order[c] * 32);
+            uint32_t td[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) td[i] = tp[i];
+            const unsigned long long k = ((unsigned long long)hamming256(qd, td) << 32) | (unsigned)c;
+            if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+        }
+        const unsigned long long m1 = wave_min_u64(k1);
+        int res = -1;
+        if (m1 != ~0ull) {
+            const unsigned long long m2 = wave_min_u64(k1 == m1 ? k2 : k1);
+            const int bestDist1 = (int)(m1 >> 32), bestDist2 = m2 == ~0ull ? 256 : (int)(m2 >> 32);
+            if (bestDist1 <= max_dist && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {   // :262-264 / :598-600
+                const int slot = (int)(uint32_t)m1;
+                if (((slot - G.t_begin) & 63) == lane) {
+                    matched[slot] = 1;
+                    if (slot - G.t_begin < 64) used0 = true;
+                }
+                res = (int)t_order[slot];
+            }
+        }
+        if (lane == 0) {
+            match_out[qi] = res;
+            int bin = 0xff;
+            if (res >= 0 && check_ori) {
+                bin = rot_bin(qangle[qi], tkeys[res].angle);
+                atomicAdd(&hist[bin], 1);
+            }
+            bin_out[qi] = (uint8_t)bin;
+        }
+    }
+}
+
+// rotation-consistency cull + count (ORBmatcher.cc:271-285 / :633-651); one workgroup
+__global__ __launch_bounds__(1024) void k_bow_cull(int nq, int check_ori, const int *__restrict__ hist,
+                                                   const uint8_t *__restrict__ bin, int *__restrict__ match, int *out_n)
+{
+    __shared__ int s_hist[HISTO_LENGTH];
+    __shared__ int s_n;
+    if (threadIdx.x < HISTO_LENGTH) s_hist[threadIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    if (check_ori) three_maxima(s_hist, ind1, ind2, ind3);
+    int cntl = 0;
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+        if (match[i] < 0) continue;
+        const int b = bin[i];
+        if (check_ori && b != ind1 && b != ind2 && b != ind3) match[i] = -1;
+        else ++cntl;
+    }
+    if (cntl) atomicAdd(&s_n, cntl);
+    __syncthreads();
+    if (threadIdx.x == 0) *out_n = s_n;
+}
+
+// SearchForTriangulation: one wavefront per query; the epipole and epipolar-line gates are applied here and only the
+// winner (smallest distance, LAST index on ties, ":735 dist>bestDist") is kept.  The reference never sets
+// vbMatched2, so queries are independent; k_resolve_par mode 4 then only does the rotation cull.
 struct TriParams {
     float f12[9];
     float ex, ey;
     float sigma2[ORBHIP_MAX_LEVELS], sf[ORBHIP_MAX_LEVELS];
 };
 
-template <bool TRI>
-__global__ __launch_bounds__(256) void k_node_search(DevFrame F, const uint32_t *__restrict__ tnode,
-                                                     const uint8_t *__restrict__ tvalid,
-                                                     const orbhip_query *__restrict__ q,
-                                                     const uint8_t *__restrict__ qdesc, int nq,
-                                                     unsigned long long *__restrict__ cand, int *__restrict__ cnt,
-                                                     int stride, TriParams P)
+__global__ __launch_bounds__(256) void k_tri_search(DevFrame F, const uint32_t *__restrict__ tnode,
+                                                    const uint8_t *__restrict__ tvalid,
+                                                    const orbhip_query *__restrict__ q,
+                                                    const uint8_t *__restrict__ qdesc, int nq,
+                                                    unsigned long long *__restrict__ cand, int *__restrict__ cnt,
+                                                    int stride, TriParams P)
 {
-    __shared__ unsigned long long stage[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int qi = blockIdx.x * 4 + wv;
     if (qi >= nq) return;
@@ -213,86 +318,42 @@ __global__ __launch_bounds__(256) void k_node_search(DevFrame F, const uint32_t 
     const uint32_t *qp = reinterpret_cast<const uint32_t *>(qdesc + (size_t)qi * 32);
 #pragma unroll
     for (int i = 0; i < 8; ++i) qd[i] = qp[i];
-    unsigned long long *out = cand + (size_t)qi * stride;
-    float la = 0.f, lb = 0.f, lc = 0.f, den = 0.f;
     const bool stereo1 = Q.ur >= 0;
-    if (TRI) {   // epipolar line of the query in image 2, ORBmatcher.cc:143-145
-        la = __fadd_rn(__fadd_rn(__fmul_rn(Q.u, P.f12[0]), __fmul_rn(Q.v, P.f12[3])), P.f12[6]);
-        lb = __fadd_rn(__fadd_rn(__fmul_rn(Q.u, P.f12[1]), __fmul_rn(Q.v, P.f12[4])), P.f12[7]);
-        lc = __fadd_rn(__fadd_rn(__fmul_rn(Q.u, P.f12[2]), __fmul_rn(Q.v, P.f12[5])), P.f12[8]);
-        den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
-    }
-    int total = 0;
+    // epipolar line of the query in image 2, ORBmatcher.cc:143-145
+    const float la = __fadd_rn(__fadd_rn(__fmul_rn(Q.u, P.f12[0]), __fmul_rn(Q.v, P.f12[3])), P.f12[6]);
+    const float lb = __fadd_rn(__fadd_rn(__fmul_rn(Q.u, P.f12[1]), __fmul_rn(Q.v, P.f12[4])), P.f12[7]);
+    const float lc = __fadd_rn(__fadd_rn(__fmul_rn(Q.u, P.f12[2]), __fmul_rn(Q.v, P.f12[5])), P.f12[8]);
+    const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
     unsigned long long best = ~0ull;
-    for (int j0 = 0; j0 < F.n; j0 += 64) {
-        const int j = j0 + lane;
-        bool ok = j < F.n && tnode[j] == qnode && (!tvalid || tvalid[j]);
-        unsigned long long key = 0;
-        if (ok) {
-            const uint32_t *tp = reinterpret_cast<const uint32_t *>(F.desc + (size_t)j * 32);
-            uint32_t td[8];
+    for (int j = lane; j < F.n; j += 64) {
+        if (tnode[j] != qnode || (tvalid && !tvalid[j])) continue;
+        const uint32_t *tp = reinterpret_cast<const uint32_t *>(F.desc + (size_t)j * 32);
+        uint32_t td[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) td[i] = tp[i];
-            const int dist = hamming256(qd, td);
-            if (TRI) {
-                ok = dist <= TH_LOW;
-                if (ok) {
-                    const orbhip_keypoint kp = F.keys[j];
-                    const bool stereo2 = F.u_right && F.u_right[j] >= 0;
-                    if (!stereo1 && !stereo2) {   // :741-747
-                        const float dx = __fsub_rn(P.ex, kp.x), dy = __fsub_rn(P.ey, kp.y);
-                        if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.f, P.sf[kp.octave])) ok = false;
-                    }
-                    if (ok) {                     // CheckDistEpipolarLine :147-156
-                        const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, kp.x), __fmul_rn(lb, kp.y)), lc);
-                        if (den == 0) ok = false;
-                        else {
-                            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
-                            ok = (double)dsqr < 3.84 * (double)P.sigma2[kp.octave];
-                        }
-                    }
-                }
-                if (ok) {
-                    const unsigned long long k = ((unsigned long long)dist << 32) | (uint32_t)(0xfffff - j);
-                    best = k < best ? k : best;
-                }
-            } else {
-                key = ((unsigned long long)dist << 32) | (uint32_t)j;
-            }
+        for (int i = 0; i < 8; ++i) td[i] = tp[i];
+        const int dist = hamming256(qd, td);
+        if (dist > TH_LOW) continue;
+        const orbhip_keypoint kp = F.keys[j];
+        const bool stereo2 = F.u_right && F.u_right[j] >= 0;
+        if (!stereo1 && !stereo2) {   // :741-747
+            const float dx = __fsub_rn(P.ex, kp.x), dy = __fsub_rn(P.ey, kp.y);
+            if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.f, P.sf[kp.octave])) continue;
         }
-        if (!TRI) {
-            const unsigned long long bal = __ballot(ok);
-            if (ok) {
-                const int pos = total + __popcll(bal & ((1ull << lane) - 1ull));
-                out[pos] = key;
-                if (pos < 64) stage[wv][pos] = key;
-            }
-            total += __popcll(bal);
-        }
+        // CheckDistEpipolarLine :147-156
+        const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, kp.x), __fmul_rn(lb, kp.y)), lc);
+        if (den == 0) continue;
+        const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+        if (!((double)dsqr < 3.84 * (double)P.sigma2[kp.octave])) continue;
+        const unsigned long long k = ((unsigned long long)dist << 32) | (uint32_t)(0xfffff - j);
+        best = k < best ? k : best;
     }
-    if (TRI) {
-        best = wave_min_u64(best);
-        if (lane == 0) {
-            if (best == ~0ull) cnt[qi] = 0;
-            else { out[0] = (best & 0xffffffff00000000ull) | (uint32_t)(0xfffff - (int)(best & 0xfffffu)); cnt[qi] = 1; }
+    best = wave_min_u64(best);
+    if (lane == 0) {
+        if (best == ~0ull) cnt[qi] = 0;
+        else {
+            cand[(size_t)qi * stride] = (best & 0xffffffff00000000ull) | (uint32_t)(0xfffff - (int)(best & 0xfffffu));
+            cnt[qi] = 1;
         }
-        return;
-    }
-    if (total > 0 && total <= 64) {
-        __builtin_amdgcn_wave_barrier();
-        unsigned long long v = lane < total ? stage[wv][lane] : ~0ull;
-        for (int k = 2; k <= 64; k <<= 1)
-            for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                unsigned long long o = __shfl_xor(v, jj, 64);
-                const bool up = ((lane & k) == 0);
-                const bool lower = ((lane & jj) == 0);
-                const unsigned long long mn = o < v ? o : v, mx = o < v ? v : o;
-                v = (lower == up) ? mn : mx;
-            }
-        if (lane < total) out[lane] = v;
-        if (lane == 0) cnt[qi] = total;
-    } else if (lane == 0) {
-        cnt[qi] = -total;
     }
 }
 
@@ -565,9 +626,8 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
     if (lane == 0) *out_n = nmatches;
 }
 
-// ---- parallel resolve: modes 0 / 1 (SearchByProjection overloads), 3 (SearchByBoW: best + second among unblocked
-// candidates, ratio test, every accepted match blocks its slot), 4 (SearchForTriangulation: one pre-gated candidate
-// per query, no blocking, output per query) --------------------------------------------------------------------
+// ---- parallel resolve: modes 0 / 1 (SearchByProjection overloads) and 4 (SearchForTriangulation: one pre-gated
+// candidate per query, no blocking, rotation cull, output per query) ---------------------------------------------
 // The sequential reference loop is the unique solution of
 //   choice(i) = first candidate of query i (in (distance, visiting order)) that is neither taken on entry
 //               nor chosen by an accepted, observed query j < i,
@@ -656,10 +716,6 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                         const int bestLevel2 = k2 == ~0ull ? -1 : (int)S.t_oct[(int)(k2 & 0xfffffu)];
                         if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) acc = false;
                     }
-                    if (acc && mode == 3) {   // SearchByBoW ratio test, ORBmatcher.cc:264 / :600
-                        const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
-                        acc = (float)bestDist < __fmul_rn(nnratio, (float)bestDist2);
-                    }
                     if (acc) newc = bestIdx;
                 }
             }
@@ -677,7 +733,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     for (int c = tid; c < n; c += T) assign[c] = -1;
     __syncthreads();
     int acc_local = 0;
-    const bool ori = (mode == 0 || mode >= 3) && check_ori;
+    const bool ori = (mode == 0 || mode == 4) && check_ori;
     for (int i = tid; i < nq; i += T) {
         const int c = S.choice[i];
         if (c < 0) continue;
@@ -1096,11 +1152,103 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
     return ORBHIP_OK;
 }
 
-// shared driver of SearchByBoW (tri == null) and SearchForTriangulation (tri != null)
-static int run_node_search(orbhip_matcher *m, const TriParams *tri, const orbhip_frame_view *f1, const uint32_t *node1,
-                           const uint8_t *valid1, const orbhip_frame_view *f2, const uint32_t *node2,
-                           const uint8_t *mask2, int only_stereo, int max_dist, float nnratio, int check_ori,
-                           int32_t *matches12, int *nmatches)
+// processing order of the reference: FeatureVector nodes ascending, feature indices ascending inside a node
+static void node_order(const uint32_t *node, const uint8_t *valid, int n, std::vector<int> &order)
+{
+    static thread_local std::vector<unsigned long long> keys;
+    keys.clear();
+    keys.reserve(n);
+    for (int i = 0; i < n; ++i)
+        if (node[i] != ORBHIP_NO_NODE && (!valid || valid[i])) keys.push_back(((unsigned long long)node[i] << 32) | (unsigned)i);
+    std::sort(keys.begin(), keys.end());
+    order.resize(keys.size());
+    for (size_t k = 0; k < keys.size(); ++k) order[k] = (int)(uint32_t)keys[k];
+}
+
+// SearchByBoW, both overloads
+static int run_bow(orbhip_matcher *m, const orbhip_frame_view *f1, const uint32_t *node1, const uint8_t *valid1,
+                   const orbhip_frame_view *f2, const uint32_t *node2, const uint8_t *blocked2, int max_dist,
+                   float nnratio, int check_ori, int32_t *matches12, int *nmatches)
+{
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    const int n1 = f1->n, n2 = f2->n;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    *nmatches = 0;
+    if (n1 == 0 || n2 == 0) return ORBHIP_OK;
+    std::vector<int> order, torder;
+    node_order(node1, valid1, n1, order);
+    node_order(node2, nullptr, n2, torder);   // blocked features keep their slot: they only start out "matched"
+    const int nq = (int)order.size(), nt = (int)torder.size();
+    if (nq == 0 || nt == 0) return ORBHIP_OK;
+    std::vector<NodeGroup> groups;            // common nodes, the merge of ORBmatcher.cc:185-286
+    for (int a = 0, b = 0; a < nq && b < nt;) {
+        const uint32_t na = node1[order[a]], nb = node2[torder[b]];
+        if (na == nb) {
+            int ae = a, be = b;
+            while (ae < nq && node1[order[ae]] == na) ++ae;
+            while (be < nt && node2[torder[be]] == na) ++be;
+            groups.push_back(NodeGroup{a, ae, b, be});
+            a = ae; b = be;
+        } else if (na < nb) ++a;
+        else ++b;
+    }
+    const int ng = (int)groups.size();
+    if (ng == 0) return ORBHIP_OK;
+    const size_t n = (size_t)n2;
+    Stage st;
+    int rc;
+    if ((rc = stage_begin(m, al256(n * sizeof(orbhip_keypoint)) + al256(n * 32) + al256((size_t)nt * 4) + al256((size_t)nt) +
+                                 al256((size_t)nq * 32) + al256((size_t)nq * 4) + al256((size_t)ng * sizeof(NodeGroup)) +
+                                 al256(HISTO_LENGTH * 4), &st))) return rc;
+    const orbhip_keypoint *d_tkeys = (const orbhip_keypoint *)st.put(f2->keys, n * sizeof(orbhip_keypoint));
+    const uint8_t *d_tdesc = (const uint8_t *)st.put(f2->desc, n * 32);
+    const uint32_t *d_torder = (const uint32_t *)st.put(torder.data(), (size_t)nt * 4);
+    uint8_t *hm = st.h + st.off;
+    uint8_t *d_matched = (uint8_t *)st.put(nullptr, 0);
+    for (int c = 0; c < nt; ++c) hm[c] = (uint8_t)(blocked2 && blocked2[torder[c]]);
+    st.off += al256((size_t)nt);
+    uint8_t *hqd = st.h + st.off;
+    const uint8_t *d_qdesc = (const uint8_t *)st.put(nullptr, 0);
+    st.off += al256((size_t)nq * 32);
+    float *hqa = reinterpret_cast<float *>(st.h + st.off);
+    const float *d_qangle = (const float *)st.put(nullptr, 0);
+    st.off += al256((size_t)nq * 4);
+    for (int p = 0; p < nq; ++p) {
+        memcpy(hqd + (size_t)p * 32, f1->desc + (size_t)order[p] * 32, 32);
+        hqa[p] = f1->keys[order[p]].angle;
+    }
+    const NodeGroup *d_groups = (const NodeGroup *)st.put(groups.data(), (size_t)ng * sizeof(NodeGroup));
+    memset(st.h + st.off, 0, HISTO_LENGTH * 4);
+    int *d_hist = (int *)st.put(nullptr, 0);
+    st.off += al256(HISTO_LENGTH * 4);
+    if ((rc = stage_commit(m, &st))) return rc;
+    void *p;
+    if ((rc = scratch(m, S_OUT, (size_t)(nq + 1) * sizeof(int), &p))) return rc;
+    int *d_out = (int *)p;
+    if ((rc = scratch(m, S_CNT, (size_t)nq, &p))) return rc;
+    uint8_t *d_bin = (uint8_t *)p;
+    uint8_t *h_out;
+    if ((rc = out_buffer(m, (size_t)(nq + 1) * sizeof(int), &h_out))) return rc;
+    // queries whose node does not occur in f2 belong to no group: they stay at -1
+    ORBHIP_HIP_CHECK(hipMemsetAsync(d_out, 0xff, (size_t)nq * sizeof(int), m->stream));
+    hipLaunchKernelGGL(k_bow_groups, dim3((ng + 3) / 4), dim3(256), 0, m->stream, d_groups, ng, d_qdesc, d_qangle, d_torder,
+                       d_tdesc, d_tkeys, d_matched, max_dist, nnratio, check_ori, d_out, d_bin, d_hist);
+    hipLaunchKernelGGL(k_bow_cull, dim3(1), dim3(1024), 0, m->stream, nq, check_ori, (const int *)d_hist,
+                       (const uint8_t *)d_bin, d_out, d_out + nq);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)(nq + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    const int *res = reinterpret_cast<const int *>(h_out);
+    for (const NodeGroup &G : groups)
+        for (int q = G.q_begin; q < G.q_end; ++q) matches12[order[q]] = res[q];
+    *nmatches = res[nq];
+    return ORBHIP_OK;
+}
+
+// SearchForTriangulation
+static int run_tri(orbhip_matcher *m, const TriParams *tri, const orbhip_frame_view *f1, const uint32_t *node1,
+                   const uint8_t *valid1, const orbhip_frame_view *f2, const uint32_t *node2, const uint8_t *valid2,
+                   int only_stereo, int check_ori, int32_t *matches12, int *nmatches)
 {
     ORBHIP_HIP_CHECK(hipSetDevice(m->device));
     const int n1 = f1->n, n2 = f2->n;
@@ -1111,15 +1259,14 @@ static int run_node_search(orbhip_matcher *m, const TriParams *tri, const orbhip
     for (int i = 0; i < n1; ++i) matches12[i] = -1;
     *nmatches = 0;
     if (n1 == 0 || n2 == 0) return ORBHIP_OK;
-    // processing order of the reference: FeatureVector nodes ascending, feature indices ascending inside a node
     std::vector<int> order;
-    order.reserve(n1);
-    for (int i = 0; i < n1; ++i) {
-        if (node1[i] == ORBHIP_NO_NODE || (valid1 && !valid1[i])) continue;
-        if (tri && only_stereo && !(f1->u_right && f1->u_right[i] >= 0)) continue;   // :706-708
-        order.push_back(i);
+    node_order(node1, valid1, n1, order);
+    if (only_stereo) {   // :706-708
+        size_t w = 0;
+        for (size_t r = 0; r < order.size(); ++r)
+            if (f1->u_right && f1->u_right[order[r]] >= 0) order[w++] = order[r];
+        order.resize(w);
     }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return node1[a] < node1[b]; });
     const int nq = (int)order.size();
     if (nq == 0) return ORBHIP_OK;
     const size_t n = (size_t)n2;
@@ -1131,20 +1278,15 @@ static int run_node_search(orbhip_matcher *m, const TriParams *tri, const orbhip
     D.n = n2; D.min_x = D.min_y = 0.f; D.inv_w = D.inv_h = 0.f;
     D.keys = (const orbhip_keypoint *)st.put(f2->keys, n * sizeof(orbhip_keypoint));
     D.desc = (const uint8_t *)st.put(f2->desc, n * 32);
-    D.u_right = (tri && f2->u_right) ? (const float *)st.put(f2->u_right, n * sizeof(float)) : nullptr;
+    D.u_right = f2->u_right ? (const float *)st.put(f2->u_right, n * sizeof(float)) : nullptr;
     const uint32_t *d_tnode = (const uint32_t *)st.put(node2, n * sizeof(uint32_t));
-    // BoW: mask2 = blocked slots, consumed by the resolve kernel; TRI: mask2 = candidate filter (+ bOnlyStereo :725-729)
-    const uint8_t *d_mask = nullptr;
-    if (tri) {
-        if (mask2 || only_stereo) {
-            uint8_t *hm = st.h + st.off;
-            d_mask = (const uint8_t *)st.put(nullptr, 0);
-            for (int j = 0; j < n2; ++j)
-                hm[j] = (uint8_t)((!mask2 || mask2[j]) && (!only_stereo || (f2->u_right && f2->u_right[j] >= 0)));
-            st.off += al256(n);
-        }
-    } else if (mask2) {
-        d_mask = (const uint8_t *)st.put(mask2, n);
+    const uint8_t *d_mask = nullptr;   // candidate filter: no map point yet (+ bOnlyStereo :725-729)
+    if (valid2 || only_stereo) {
+        uint8_t *hm = st.h + st.off;
+        d_mask = (const uint8_t *)st.put(nullptr, 0);
+        for (int j = 0; j < n2; ++j)
+            hm[j] = (uint8_t)((!valid2 || valid2[j]) && (!only_stereo || (f2->u_right && f2->u_right[j] >= 0)));
+        st.off += al256(n);
     }
     orbhip_query *hq = reinterpret_cast<orbhip_query *>(st.h + st.off);
     const orbhip_query *d_q = (const orbhip_query *)st.put(nullptr, 0);
@@ -1165,42 +1307,27 @@ static int run_node_search(orbhip_matcher *m, const TriParams *tri, const orbhip
     }
     if ((rc = stage_commit(m, &st))) return rc;
     void *p;
-    const int stride = tri ? 2 : ((n2 + 1) & ~1);
+    const int stride = 2;
     if ((rc = scratch(m, S_CAND, (size_t)nq * stride * sizeof(unsigned long long), &p))) return rc;
     unsigned long long *d_cand = (unsigned long long *)p;
     if ((rc = scratch(m, S_CNT, (size_t)nq * sizeof(int), &p))) return rc;
     int *d_cnt = (int *)p;
-    const int nout = tri ? nq : n2;
-    if ((rc = scratch(m, S_OUT, (size_t)(nout + 1) * sizeof(int), &p))) return rc;
+    if ((rc = scratch(m, S_OUT, (size_t)(nq + 1) * sizeof(int), &p))) return rc;
     int *d_out = (int *)p;
     uint8_t *h_out;
-    if ((rc = out_buffer(m, (size_t)(nout + 1) * sizeof(int), &h_out))) return rc;
+    if ((rc = out_buffer(m, (size_t)(nq + 1) * sizeof(int), &h_out))) return rc;
     const Batch one = {nullptr, nullptr, 0, 0};
     if ((rc = ensure_resolve_attr(m))) return rc;
-    if (tri) {
-        hipLaunchKernelGGL(k_node_search<true>, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_tnode, d_mask, d_q, d_qdesc,
-                           nq, d_cand, d_cnt, stride, *tri);
-        hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), sizeof(ResolveParShared), m->stream, 4, D, d_q, nq, d_cand, d_cnt,
-                           stride, (const uint8_t *)nullptr, 0.f, check_ori, d_out, d_out + nout, one, TH_LOW, 0);
-    } else {
-        TriParams none;
-        memset(&none, 0, sizeof(none));
-        hipLaunchKernelGGL(k_node_search<false>, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_tnode,
-                           (const uint8_t *)nullptr, d_q, d_qdesc, nq, d_cand, d_cnt, stride, none);
-        hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), sizeof(ResolveParShared), m->stream, 3, D, d_q, nq, d_cand, d_cnt,
-                           stride, d_mask, nnratio, check_ori, d_out, d_out + nout, one, max_dist, 1);
-    }
+    hipLaunchKernelGGL(k_tri_search, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_tnode, d_mask, d_q, d_qdesc, nq,
+                       d_cand, d_cnt, stride, *tri);
+    hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), sizeof(ResolveParShared), m->stream, 4, D, d_q, nq, d_cand, d_cnt,
+                       stride, (const uint8_t *)nullptr, 0.f, check_ori, d_out, d_out + nq, one, TH_LOW, 0);
     ORBHIP_HIP_CHECK(hipGetLastError());
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)(nout + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)(nq + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
     const int *res = reinterpret_cast<const int *>(h_out);
-    if (tri) {
-        for (int q = 0; q < nq; ++q) matches12[order[q]] = res[q];
-    } else {
-        for (int j = 0; j < n2; ++j)
-            if (res[j] >= 0) matches12[order[res[j]]] = j;
-    }
-    *nmatches = res[nout];
+    for (int q = 0; q < nq; ++q) matches12[order[q]] = res[q];
+    *nmatches = res[nq];
     return ORBHIP_OK;
 }
 
@@ -1317,8 +1444,7 @@ int orbhip_search_by_bow(orbhip_matcher *m, const orbhip_frame_view *f1, const u
     if (!m || !f1 || !f2 || !matches12 || !nmatches || f1->n < 0 || f2->n < 0) return ORBHIP_E_ARG;
     if ((f1->n > 0 && (!node1 || !f1->keys || !f1->desc)) || (f2->n > 0 && (!node2 || !f2->keys || !f2->desc)))
         return ORBHIP_E_ARG;
-    return run_node_search(m, nullptr, f1, node1, valid1, f2, node2, blocked2, 0, max_dist, nnratio, check_ori, matches12,
-                           nmatches);
+    return run_bow(m, f1, node1, valid1, f2, node2, blocked2, max_dist, nnratio, check_ori, matches12, nmatches);
 }
 
 int orbhip_search_for_triangulation(orbhip_matcher *m, const orbhip_frame_view *f1, const uint32_t *node1,
@@ -1344,8 +1470,7 @@ int orbhip_search_for_triangulation(orbhip_matcher *m, const orbhip_frame_view *
             set_error("search_for_triangulation: keypoint %d has octave %d outside [0,%d)", j, f2->keys[j].octave, f2->n_levels);
             return ORBHIP_E_ARG;
         }
-    return run_node_search(m, &P, f1, node1, valid1, f2, node2, valid2, only_stereo, TH_LOW, 0.f, check_ori, matches12,
-                           nmatches);
+    return run_tri(m, &P, f1, node1, valid1, f2, node2, valid2, only_stereo, check_ori, matches12, nmatches);
 }
 
 int orbhip_search_best_in_window(orbhip_matcher *m, const orbhip_frame_view *kf, const orbhip_query *q,

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import assert_kps_equal, synth_frame
+from helpers import assert_kps_equal, frame_bounds, make_vocabulary, synth_frame, write_vocabulary
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -31,7 +31,9 @@ def test_cpp_shim_matches_oracle(tmp_path, oracle):
     img = synth_frame(3, 640, 480)
     raw, out = str(tmp_path / "in.raw"), str(tmp_path / "out.bin")
     img.tofile(raw)
-    r = subprocess.run([exe, raw, "480", "640", "800", out], capture_output=True, text=True)
+    vpath = write_vocabulary(tmp_path / "voc.txt", make_vocabulary(10, 3, seed=2))
+    out2 = str(tmp_path / "bow.bin")
+    r = subprocess.run([exe, raw, "480", "640", "800", out, str(vpath), out2], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     buf = open(out, "rb").read()
     n = int(np.frombuffer(buf[:4], np.int32)[0])
@@ -40,3 +42,20 @@ def test_cpp_shim_matches_oracle(tmp_path, oracle):
     okps, odesc = oracle.OracleExtractor(800, 1.2, 8, 20, 7).extract(img)
     assert_kps_equal(kps, okps)
     assert np.array_equal(desc, odesc)
+    # ORBVocabulary::transform + ORBmatcher::SearchByBoW through the C++ mirror
+    ov = oracle.OracleVocabulary(vpath).transform(odesc, 4)
+    b = open(out2, "rb").read()
+    nb = int(np.frombuffer(b[:4], np.int32)[0])
+    rec = np.frombuffer(b[4:4 + 12 * nb], np.dtype([("id", "<u4"), ("val", "<f8")]))
+    assert np.array_equal(rec["id"], ov["bow_ids"]) and np.array_equal(rec["val"], ov["bow_vals"])
+    off = 4 + 12 * nb
+    node = np.frombuffer(b[off:off + 4 * n], np.uint32)
+    assert np.array_equal(node, ov["node_id"])
+    off += 4 * n
+    nm = int(np.frombuffer(b[off:off + 4], np.int32)[0])
+    m12 = np.frombuffer(b[off + 4:off + 4 + 4 * n], np.int32)
+    keep = []
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    of = oracle.make_frame(okps, odesc, None, frame_bounds(img), sf, keep)
+    on, om12 = oracle.search_by_bow(of, node, None, of, node, None, 50, 0.7, True)
+    assert nm == on and np.array_equal(m12, om12)

@@ -480,7 +480,7 @@ def test_search_by_bow_random_collisions(env):
     pkg, M, O = env
     rng = np.random.default_rng(77)
     sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
-    for n1, n2, n_nodes in ((900, 1100, 3), (4096, 4096, 40), (1, 1, 1), (300, 2, 2)):
+    for n1, n2, n_nodes in ((900, 1100, 3), (4096, 4096, 40), (1, 1, 1), (300, 2, 2), (6000, 9000, 11)):
         base = rng.integers(0, 256, (40, 32), dtype=np.uint8)
         def noisy(n):
             d = base[rng.integers(0, len(base), n)].copy()
@@ -505,11 +505,12 @@ def test_search_by_bow_random_collisions(env):
             n, m12 = m.SearchByBoW(g1, node1, None, g2, node2, None, max_dist)
             on, om12 = O.search_by_bow(o1, node1, None, o2, node2, None, max_dist, nnratio, ori)
             assert n == on and np.array_equal(m12, om12)
-    # capacity error instead of silent truncation
+    # SearchForTriangulation keeps per-query state in LDS: capacity error instead of silent truncation
     big = np.zeros(4097, pkg.KP_DTYPE)
     gb = pkg.FrameView(big, np.zeros((4097, 32), np.uint8), sf, (0, 0, 640, 480))
-    with pytest.raises(Exception):
-        pkg.ORBmatcher().SearchByBoW(gb, np.zeros(4097, np.uint32), None, gb, np.zeros(4097, np.uint32))
+    with pytest.raises(pkg.OrbHipError):
+        pkg.ORBmatcher().SearchForTriangulation(gb, np.zeros(4097, np.uint32), None, gb, np.zeros(4097, np.uint32), None,
+                                                np.eye(3, dtype=np.float32), (0, 0), sf * sf)
 
 
 @pytest.mark.parametrize("W,H,nf,only_stereo", [(1241, 376, 2000, False), (752, 480, 1500, False), (1241, 376, 2000, True)])

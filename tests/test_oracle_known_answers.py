@@ -362,3 +362,68 @@ def test_search_for_triangulation_hand_worked(oracle):
     far = z.copy(); far[:7] = 0xFF                   # 56 bits > TH_LOW
     f2f, k2f = _mini_frame(oracle, [(90, 50)], [far])
     assert oracle.search_for_triangulation(f1, [3], None, f2f, [3], None, F_rows, 1000.0, 1000.0, sigma2, False, False)[0] == 0
+
+
+def test_vocabulary_transform_hand_worked(oracle, tmp_path):
+    """k=2, L=2 tree written in the DBoW2 text format; words, FeatureVector nodes and the L1-normalised tf-idf
+    BowVector worked by hand from TemplatedVocabulary.h:1127-1262 and BowVector.cpp:36-88."""
+    z, ff = [0] * 32, [255] * 32
+    a2 = [0x0F] + [0] * 31
+    b1 = [255] * 31 + [0xF0]
+    rows = [(0, 0, z, 0.0), (0, 0, ff, 0.0),              # node 1 = A, node 2 = B
+            (1, 1, z, 1.0), (1, 1, a2, 2.0),              # node 3 = word 0, node 4 = word 1
+            (2, 1, b1, 0.0), (2, 1, ff, 4.0)]             # node 5 = word 2 (stopped), node 6 = word 3
+    path = tmp_path / "voc.txt"
+    with open(path, "w") as f:
+        f.write("2 2 0 0\n")
+        for p, leaf, d, w in rows:
+            f.write("%d %d %s %r\n" % (p, leaf, " ".join(map(str, d)), w))
+    voc = oracle.OracleVocabulary(path)
+    assert voc.info() == dict(k=2, L=2, scoring=0, weighting=0, n_nodes=7, n_words=4)
+    feats = np.array([z, [1] + [0] * 31, [0x07] + [0] * 31, b1, ff], np.uint8)
+    # feature 2 (3 bits): A (3 < 253); then word 0 at distance 3 vs word 1 at distance 1 -> word 1
+    r = voc.transform(feats, levelsup=1)
+    assert r["word_id"].tolist() == [0, 0, 1, 2, 3]
+    assert r["word_weight"].tolist() == [1.0, 1.0, 2.0, 0.0, 4.0]
+    assert r["node_id"].tolist() == [1, 1, 1, oracle.NO_NODE, 2]
+    assert r["bow_ids"].tolist() == [0, 1, 3]
+    assert r["bow_vals"].tolist() == [0.25, 0.25, 0.5]               # (1+1, 2, 4) / 8
+    assert voc.transform(feats, levelsup=2)["node_id"].tolist() == [0, 0, 0, oracle.NO_NODE, 0]   # root
+    assert voc.transform(feats, levelsup=0)["node_id"].tolist() == [3, 3, 4, oracle.NO_NODE, 6]  # the words' nodes
+    # ties go to the first child: a feature equidistant from A and B (128 bits) descends into A
+    half = np.array([[255] * 16 + [0] * 16], np.uint8)
+    assert voc.transform(half, 1)["node_id"].tolist() == [1]
+    assert voc.transform(np.zeros((0, 32), np.uint8))["bow_ids"].size == 0
+    # malformed files are rejected like loadFromTextFile's header check (:1362-1366)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("25 2 0 0\n0 1 " + " ".join(["0"] * 32) + " 1.0\n")
+    with pytest.raises(ValueError):
+        oracle.OracleVocabulary(bad)
+
+
+def test_vocabulary_weighting_and_scoring_variants(oracle, tmp_path):
+    from helpers import make_vocabulary, write_vocabulary
+    rng = np.random.default_rng(3)
+    feats = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+    base = None
+    for scoring, weighting in ((0, 0), (1, 0), (5, 0), (0, 2), (5, 1), (2, 3)):
+        v = make_vocabulary(4, 3, seed=11, scoring=scoring, weighting=weighting)
+        voc = oracle.OracleVocabulary(write_vocabulary(tmp_path / ("v%d%d.txt" % (scoring, weighting)), v))
+        r = voc.transform(feats)
+        if base is None:
+            base = r
+        assert np.array_equal(r["word_id"], base["word_id"])          # the descent ignores scoring / weighting
+        keep = r["word_weight"] > 0
+        ids = np.unique(r["word_id"][keep])
+        assert np.array_equal(r["bow_ids"], ids)
+        if weighting in (0, 1):
+            raw = np.array([r["word_weight"][keep & (r["word_id"] == i)].sum() for i in ids])
+        else:
+            raw = np.array([r["word_weight"][keep & (r["word_id"] == i)][0] for i in ids])
+        if scoring == 5:
+            want = raw / len(ids) if weighting in (0, 1) else raw
+        elif scoring == 1:
+            want = raw / np.sqrt((raw * raw).sum())
+        else:
+            want = raw / np.abs(raw).sum()
+        assert np.allclose(r["bow_vals"], want, rtol=1e-12, atol=0)

@@ -75,4 +75,73 @@ out["extract_single_gpu_ms"] = timeit(lambda: ext(img0))
 frames = np.stack([synth_frame(1 + i % 8) for i in range(64)])
 out["extract_batch64_host_ms"] = timeit(lambda: ext.extract_batch(frames), 5)
 out["extract_batch64_host_fps"] = 64 / out["extract_batch64_host_ms"] * 1e3
+# Frame::ComputeBoW + SearchByBoW (reference-key-frame tracking / relocalisation chain), ORBvoc-shaped tree k=10
+def regular_tree(k, L, seed):
+    """Vectorised regular k-ary tree in saveToTextFile (BFS) order; children = parent with 48>>depth random bit flips."""
+    rng = np.random.default_rng(seed)
+    parent, leaf, desc = [], [], []
+    prev_desc, prev_first = rng.integers(0, 256, (1, 32), dtype=np.uint8), 0
+    nid = 1
+    for depth in range(1, L + 1):
+        n = prev_desc.shape[0] * k
+        d = np.repeat(prev_desc, k, axis=0)
+        for _ in range(max(2, 48 >> depth)):
+            bit = rng.integers(0, 256, n)
+            d[np.arange(n), bit >> 3] ^= (1 << (bit & 7)).astype(np.uint8)
+        parent.append(np.repeat(np.arange(prev_first, prev_first + prev_desc.shape[0], dtype=np.int32), k))
+        leaf.append(np.full(n, depth == L, np.uint8))
+        desc.append(d)
+        prev_desc, prev_first = d, nid
+        nid += n
+    parent, leaf, desc = np.concatenate(parent), np.concatenate(leaf), np.concatenate(desc)
+    weight = np.where(leaf == 1, rng.uniform(0.5, 12.0, len(leaf)), 0.0)
+    return parent, leaf, desc, weight
+
+
+from helpers import write_vocabulary  # noqa: E402
+import tempfile  # noqa: E402
+for L in (5, 6):
+    par, leaf, vdesc, wgt = regular_tree(10, L, 1)
+    voc = pkg.ORBVocabulary.from_arrays(10, L, 0, 0, par, leaf, vdesc, wgt)
+    near = vdesc[leaf == 1][np.random.default_rng(2).integers(0, int(leaf.sum()), len(d0))].copy()   # descend to full depth
+    near[:, 5] ^= 0x11
+    out["bow_transform_L%d_gpu_ms" % L] = timeit(lambda: voc.transform(near, 4))
+    if L == 6:   # levelsup 4 -> 100 FeatureVector nodes, as with ORBvoc.txt
+        r0, r1 = voc.transform(d0, 4), voc.transform(d1, 4)
+        gk0 = pkg.FrameView(k0, d0, sf, b)
+        mb = pkg.ORBmatcher(0.7, True)
+        out["search_by_bow_gpu_ms"] = timeit(lambda: mb.SearchByBoW(gk0, r0["node_id"], None, gv, r1["node_id"], None, 50))
+        ok0 = O.make_frame(k0, d0, None, b, sf, keep)
+        out["search_by_bow_cpu1_ms"] = timeit(lambda: O.search_by_bow(ok0, r0["node_id"], None, ov, r1["node_id"], None, 50, 0.7, True), 5)
+        out["search_by_bow_matches"] = int(mb.SearchByBoW(gk0, r0["node_id"], None, gv, r1["node_id"], None, 50)[0])
+        out["search_by_bow_nodes"] = int(len(np.unique(r0["node_id"])))
+    if L == 5:
+        with tempfile.TemporaryDirectory() as td:
+            ovoc = O.OracleVocabulary(write_vocabulary(os.path.join(td, "voc.txt"), dict(
+                k=10, L=L, scoring=0, weighting=0, parent=par, is_leaf=leaf, desc=vdesc, weight=wgt)))
+        out["bow_transform_L5_cpu1_ms"] = timeit(lambda: ovoc.transform(near, 4), 5)
+        # device-resident batch: 64 frames x cap features, timed with HIP events
+        import torch
+        B, cap = 64, 1280
+        dev = torch.device("cuda:0")
+        reps = (cap + len(near) - 1) // len(near)
+        dd = torch.from_numpy(np.tile(near, (reps, 1))[:cap]).to(dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+        dn = torch.full((B,), len(near) if len(near) < cap else cap, dtype=torch.int32, device=dev)
+        bufs = [torch.zeros((B, cap), dtype=dt, device=dev) for dt in (torch.int32, torch.float64, torch.int32, torch.int32, torch.float64)]
+        dnb = torch.zeros(B, dtype=torch.int32, device=dev)
+        stream = torch.cuda.Stream()
+        voc.set_stream(stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            def run():
+                voc.transform_device(B, dd.data_ptr(), dn.data_ptr(), cap, 4, bufs[0].data_ptr(), bufs[1].data_ptr(),
+                                     bufs[2].data_ptr(), bufs[3].data_ptr(), bufs[4].data_ptr(), dnb.data_ptr())
+            run(); stream.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(20):
+                run()
+            e1.record(stream); stream.synchronize()
+        out["bow_transform_device_batch64_ms"] = e0.elapsed_time(e1) / 20
+        out["bow_transform_device_fps"] = B / out["bow_transform_device_batch64_ms"] * 1e3
+        voc.set_stream(0)
 print(json.dumps({k: round(v, 3) for k, v in out.items()}))
