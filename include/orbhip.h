@@ -25,6 +25,7 @@
  *                                     (src/ORBmatcher.cc:290-403, loop closing)
  *   orbhip_search_best_in_window      inner search of ORBmatcher::Fuse x2 (src/ORBmatcher.cc:825-1100) and of both
  *                                     directions of SearchBySim3 (:1102-1326)
+ *   orbhip_distinctive_descriptors    MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307), batched
  *   orbhip_vocabulary_*               ORBVocabulary (DBoW2::TemplatedVocabulary<FORB>) loadFromTextFile + transform,
  *                                     i.e. Frame::ComputeBoW (src/Frame.cc:395-402)
  *   orbhip_search_by_bow              ORBmatcher::SearchByBoW(KeyFrame*,Frame&,..) (src/ORBmatcher.cc:159-288) and
@@ -241,6 +242,14 @@ int orbhip_search_for_triangulation(orbhip_matcher *m, const orbhip_frame_view *
                                     const uint8_t *valid2, const float *f12, float ex, float ey,
                                     const float *level_sigma2, int only_stereo, int check_ori, int32_t *matches12,
                                     int *nmatches);
+
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307), batched: map point p owns the observed
+ * descriptors desc[offsets[p] .. offsets[p+1]) (32 bytes each, in the order the reference collects them, i.e.
+ * std::map<KeyFrame*,size_t> order without bad key frames).  best_idx[p] = index inside that range of the descriptor
+ * with the least median Hamming distance to the others (vDists[0.5*(N-1)], first minimum), -1 for an empty range.
+ * At most 2048 observations per map point (ORBHIP_E_CAPACITY otherwise). */
+int orbhip_distinctive_descriptors(orbhip_matcher *m, const uint8_t *desc, const int32_t *offsets, int npoints,
+                                   int32_t *best_idx);
 
 /* ---- DBoW2 vocabulary: ORBVocabulary::loadFromTextFile + transform ---------------------------------------------
  * Replaces, for Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:395-402, src/KeyFrame.cc ComputeBoW), the

@@ -101,6 +101,7 @@ def lib():
         L.oracle_vocabulary_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 6
         L.oracle_vocabulary_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
         L.oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                     C.c_void_p, C.c_int, C.POINTER(Pyramids),
                                                     C.c_int, C.c_float, C.c_float, C.c_void_p,
@@ -333,6 +334,12 @@ def search_for_triangulation(f1, node1, valid1, f2, node2, valid2, F12, ex, ey, 
     n = lib().oracle_search_for_triangulation(C.byref(f1), _p(n1a), _p(v1), C.byref(f2), _p(n2a), _p(v2), _p(F),
                                               float(ex), float(ey), _p(sg), int(only_stereo), int(check_ori), _p(m12))
     return n, m12[:f1.n].copy()
+
+
+def distinctive_descriptor(desc):
+    """MapPoint::ComputeDistinctiveDescriptors for one map point; index of the chosen observation or -1."""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    return lib().oracle_distinctive_descriptor(_p(d), len(d))
 
 
 def compute_stereo_matches(keys_l, desc_l, keys_r, desc_r, levels_l, levels_r, scale, inv_scale,

@@ -1336,6 +1336,26 @@ int oracle_compute_stereo_matches(const oracle_kp *kl, const uint8_t *dl, int N,
     return nm;
 }
 
+/* MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:272-307: all-pairs Hamming distances between the N
+ * observations of a map point; the descriptor with the least median distance (vDists[0.5*(N-1)] of the sorted row,
+ * self distance included) wins, first minimum on ties.  Returns the index or -1 for N == 0. */
+static int int_cmp(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+int oracle_distinctive_descriptor(const uint8_t *desc, int N)
+{
+    if (N <= 0) return -1;
+    int *row = (int *)malloc(sizeof(int) * (size_t)N);
+    int BestMedian = INT_MAX, BestIdx = 0;
+    for (int i = 0; i < N; ++i) {
+        for (int j = 0; j < N; ++j)
+            row[j] = i == j ? 0 : oracle_descriptor_distance(desc + (size_t)i * 32, desc + (size_t)j * 32);
+        qsort(row, N, sizeof(int), int_cmp);
+        const int median = row[(int)(0.5 * (N - 1))];
+        if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+    }
+    free(row);
+    return BestIdx;
+}
+
 /* ---- DBoW2 vocabulary: loadFromTextFile + transform --------------------------------------------------------
  * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424 (text format), :1127-1199 (transform of a feature set),
  * :1218-1262 (descent of one feature), BowVector.cpp:36-88 (addWeight / addIfNotExist / normalize),

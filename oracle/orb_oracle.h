@@ -164,6 +164,9 @@ int oracle_search_for_triangulation(const oracle_frame *f1, const uint32_t *node
                                     const float *F12, float ex, float ey, const float *level_sigma2,
                                     int only_stereo, int check_ori, int32_t *matches12);
 
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:242-307) for one map point with N observed descriptors */
+int oracle_distinctive_descriptor(const uint8_t *desc, int N);
+
 /* DBoW2 vocabulary (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h): loadFromTextFile :1338-1424 and
  * transform(features, BowVector, FeatureVector, levelsup) :1127-1199 as called by Frame::ComputeBoW (Frame.cc:395-402,
  * levelsup = 4).  Returns the BowVector size; per-feature word id / weight / FeatureVector node id, and the

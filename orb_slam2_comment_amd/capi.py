@@ -71,6 +71,7 @@ SYMBOLS = [
     ("orbhip_search_by_bow", _i, [_vp, C.POINTER(FrameView), _vp, _vp, C.POINTER(FrameView), _vp, _vp, _i, _f, _i, _vp, _pi]),
     ("orbhip_search_for_triangulation", _i, [_vp, C.POINTER(FrameView), _vp, _vp, C.POINTER(FrameView), _vp, _vp, _vp, _f,
                                              _f, _vp, _i, _i, _vp, _pi]),
+    ("orbhip_distinctive_descriptors", _i, [_vp, _vp, _vp, _i, _vp]),
     ("orbhip_vocabulary_load_text", _i, [C.c_char_p, _i, C.POINTER(_vp)]),
     ("orbhip_vocabulary_create", _i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp)]),
     ("orbhip_vocabulary_destroy", None, [_vp]),

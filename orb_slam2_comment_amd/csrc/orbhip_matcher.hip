@@ -780,6 +780,64 @@ __global__ void k_distance_matrix(const uint8_t *__restrict__ a, int na, const u
     dist[(size_t)i * nb + j] = d;
 }
 
+// ---- MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:242-307), batched over map points ----------------
+// One wavefront per map point with N observations: for every row i the lanes hold the distances d(i, j); the
+// median vDists[0.5*(N-1)] of the sorted row (self distance 0 included) is the k-th smallest value, found by a
+// 9-step bisection on the value range [0, 256] with ballot/popcount counting (rows longer than 64 keep their
+// distances in LDS).  Smallest median wins, first index on ties (:296-300).
+constexpr int kDistinctMax = 2048;
+
+__global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__ desc, const int *__restrict__ offsets,
+                                                     int npoints, int *__restrict__ best)
+{
+    __shared__ unsigned short srow[4][kDistinctMax];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = blockIdx.x * 4 + wv;
+    if (p >= npoints) return;
+    const int o0 = offsets[p], N = offsets[p + 1] - o0;
+    if (N <= 0) { if (lane == 0) best[p] = -1; return; }
+    const uint8_t *D = desc + (size_t)o0 * 32;
+    const int k = (N - 1) >> 1;   // (int)(0.5*(N-1))
+    uint32_t t0[8];
+    {
+        const uint32_t *tp = reinterpret_cast<const uint32_t *>(D + (size_t)(lane < N ? lane : 0) * 32);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t0[w] = tp[w];
+    }
+    int bestMedian = INT_MAX, bestIdx = 0;
+    for (int i = 0; i < N; ++i) {
+        uint32_t di[8];
+        const uint32_t *ip = reinterpret_cast<const uint32_t *>(D + (size_t)i * 32);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) di[w] = ip[w];
+        const int d0 = lane < N ? hamming256(di, t0) : 0x7fff;
+        if (N > 64) {
+            for (int j = lane + 64; j < N; j += 64) {
+                const uint32_t *tp = reinterpret_cast<const uint32_t *>(D + (size_t)j * 32);
+                uint32_t t[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) t[w] = tp[w];
+                srow[wv][j] = (unsigned short)hamming256(di, t);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        int lo = 0, hi = 256;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = __popcll(__ballot(d0 <= mid));
+            if (N > 64) {
+                int c = 0;
+                for (int j = lane + 64; j < N; j += 64) c += srow[wv][j] <= mid;
+                cnt += wave_reduce_add_i(c);
+            }
+            if (cnt >= k + 1) hi = mid; else lo = mid + 1;
+        }
+        if (lo < bestMedian) { bestMedian = lo; bestIdx = i; }
+        if (N > 64) __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) best[p] = bestIdx;
+}
+
 // ---- Frame::ComputeStereoMatches (Frame.cc:466-640) -----------------------------------------
 struct StereoGeom {
     int nlevels, nrows;
@@ -1435,6 +1493,41 @@ int orbhip_search_by_projection_sim3(orbhip_matcher *m, const orbhip_frame_view 
 {
     if (!m || !kf || (nq > 0 && (!q || !qdesc)) || !assign || !nmatches || nq < 0) return ORBHIP_E_ARG;
     return run_search(m, 0, kf, q, qdesc, nullptr, nq, matched, 0.f, 0, assign, kf->n, nmatches, TH_LOW, 1, 0);
+}
+
+int orbhip_distinctive_descriptors(orbhip_matcher *m, const uint8_t *desc, const int32_t *offsets, int npoints,
+                                   int32_t *best_idx)
+{
+    if (!m || npoints < 0 || (npoints > 0 && (!offsets || !best_idx))) return ORBHIP_E_ARG;
+    if (npoints == 0) return ORBHIP_OK;
+    if (offsets[0] < 0) return ORBHIP_E_ARG;
+    for (int p = 0; p < npoints; ++p) {
+        const long long N = (long long)offsets[p + 1] - offsets[p];
+        if (N < 0) { set_error("distinctive_descriptors: offsets must be non-decreasing (point %d)", p); return ORBHIP_E_ARG; }
+        if (N > kDistinctMax) {
+            set_error("distinctive_descriptors: map point %d has %lld observations (limit %d)", p, N, kDistinctMax);
+            return ORBHIP_E_CAPACITY;
+        }
+    }
+    const size_t total = (size_t)offsets[npoints];
+    if (total > 0 && !desc) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    Stage st;
+    int rc;
+    if ((rc = stage_begin(m, al256(total * 32) + al256((size_t)(npoints + 1) * 4), &st))) return rc;
+    const uint8_t *d_desc = (const uint8_t *)st.put(desc, total * 32);
+    const int *d_off = (const int *)st.put(offsets, (size_t)(npoints + 1) * 4);
+    if ((rc = stage_commit(m, &st))) return rc;
+    void *p;
+    if ((rc = scratch(m, S_OUT, (size_t)npoints * sizeof(int), &p))) return rc;
+    uint8_t *h_out;
+    if ((rc = out_buffer(m, (size_t)npoints * sizeof(int), &h_out))) return rc;
+    hipLaunchKernelGGL(k_distinctive, dim3((npoints + 3) / 4), dim3(256), 0, m->stream, d_desc, d_off, npoints, (int *)p);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, p, (size_t)npoints * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    memcpy(best_idx, h_out, (size_t)npoints * sizeof(int));
+    return ORBHIP_OK;
 }
 
 int orbhip_search_by_bow(orbhip_matcher *m, const orbhip_frame_view *f1, const uint32_t *node1, const uint8_t *valid1,

@@ -193,6 +193,20 @@ class ORBmatcher:
                                                         C.byref(nm)), "orbhip_search_for_triangulation")
         return nm.value, m12[:F1.N].copy()
 
+    def ComputeDistinctiveDescriptors(self, descriptor_lists):
+        """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307) for a batch of map points.
+        descriptor_lists: sequence of (N_p x 32) uint8 arrays; returns best index per map point (-1 if empty)."""
+        lens = [len(np.asarray(d).reshape(-1, 32)) for d in descriptor_lists]
+        off = np.zeros(len(lens) + 1, np.int32)
+        off[1:] = np.cumsum(lens)
+        flat = (np.concatenate([np.asarray(d, np.uint8).reshape(-1, 32) for d in descriptor_lists])
+                if off[-1] > 0 else np.zeros((1, 32), np.uint8))
+        flat = np.ascontiguousarray(flat, np.uint8)
+        best = np.full(max(len(lens), 1), -1, np.int32)
+        check(self._lib.orbhip_distinctive_descriptors(self._h, ptr(flat), ptr(off), len(lens), ptr(best)),
+              "orbhip_distinctive_descriptors")
+        return best[:len(lens)].copy()
+
     # -- device-resident, batched SearchByProjection ---------------------------
     def set_stream(self, stream):
         check(self._lib.orbhip_matcher_set_stream(self._h, stream), "orbhip_matcher_set_stream")

@@ -553,3 +553,32 @@ def test_search_for_triangulation(env, W, H, nf, only_stereo):
     n0, m0 = pkg.ORBmatcher(0.6, True).SearchForTriangulation(g1, node1, None, g2, node2, None, np.zeros(9, np.float32),
                                                               (0, 0), sigma2)
     assert n0 == 0 and (m0 == -1).all()            # den == 0 -> CheckDistEpipolarLine false (:152-153)
+
+
+def test_distinctive_descriptors(env):
+    """MapPoint::ComputeDistinctiveDescriptors batched over map points: same chosen observation as the oracle,
+    for short (N <= 64, register path) and long (LDS path) observation lists, with duplicates forcing median ties."""
+    pkg, M, O = env
+    rng = np.random.default_rng(12)
+    base = rng.integers(0, 256, (30, 32), dtype=np.uint8)
+    lists = []
+    for N in [0, 1, 2, 3, 4, 5, 8, 17, 63, 64, 65, 100, 129, 300, 2048] + list(rng.integers(1, 40, 200)):
+        d = base[rng.integers(0, 30, N)].copy()
+        if N:
+            noise = rng.integers(0, 256, (N, 32), dtype=np.uint8) & rng.integers(0, 256, (N, 32), dtype=np.uint8) \
+                & rng.integers(0, 256, (N, 32), dtype=np.uint8)
+            d ^= noise * (rng.random((N, 1)) < 0.6)
+        lists.append(d)
+    m = pkg.ORBmatcher()
+    got = m.ComputeDistinctiveDescriptors(lists)
+    want = np.array([O.distinctive_descriptor(d) for d in lists], np.int32)
+    assert np.array_equal(got, want)
+    assert got[0] == -1 and got[1] == 0
+    # independent numpy check of the definition on one list
+    d = lists[12].astype(np.uint8)
+    dist = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(2)
+    med = np.sort(dist, axis=1)[:, int(0.5 * (len(d) - 1))]
+    assert got[12] == int(np.argmin(med))
+    with pytest.raises(pkg.OrbHipError):
+        m.ComputeDistinctiveDescriptors([np.zeros((2049, 32), np.uint8)])
+    assert len(m.ComputeDistinctiveDescriptors([])) == 0

@@ -427,3 +427,20 @@ def test_vocabulary_weighting_and_scoring_variants(oracle, tmp_path):
         else:
             want = raw / np.abs(raw).sum()
         assert np.allclose(r["bow_vals"], want, rtol=1e-12, atol=0)
+
+
+def test_distinctive_descriptor_hand_worked(oracle):
+    """MapPoint.cc:287-301: medians of the sorted rows (self distance included), first minimum."""
+    z = np.zeros(32, np.uint8)
+    a = z.copy(); a[0] = 0b1            # 1 bit
+    b = z.copy(); b[0] = 0b111          # 3 bits
+    c = z.copy(); c[:2] = 0xFF          # 16 bits
+    # rows: z:[0,1,3,16] a:[0,1,2,15] b:[0,2,3,13] c:[0,13,15,16]; index 0.5*3 -> 1: medians 1,1,2,13 -> first = 0
+    assert oracle.distinctive_descriptor(np.stack([z, a, b, c])) == 0
+    # N=3 -> index 1: z:[0,3,16]->3, b:[0,3,13]->3, c:[0,13,16]->13 -> first of the tie = 0; reversed order -> b (idx 1)
+    assert oracle.distinctive_descriptor(np.stack([z, b, c])) == 0
+    assert oracle.distinctive_descriptor(np.stack([c, b, z])) == 1
+    assert oracle.distinctive_descriptor(np.stack([c])) == 0
+    assert oracle.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == -1
+    # N=2 -> index 0 -> every median is the self distance 0 -> first observation
+    assert oracle.distinctive_descriptor(np.stack([c, z])) == 0
