@@ -199,9 +199,9 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ 
 __device__ __forceinline__ uint32_t resize_px(const uint8_t *S0, const uint8_t *S1, int sx, int a0, int a1, int b0, int b1)
 {
     // sx+1 may be the first border byte when sx == sw-1; a1 is 0 there.
-    const int r0 = S0[sx] * a0 + S0[sx + 1] * a1;
-    const int r1 = S1[sx] * a0 + S1[sx + 1] * a1;
-    return (uint32_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+    const int r0 = __mul24(S0[sx], a0) + __mul24(S0[sx + 1], a1);
+    const int r1 = __mul24(S1[sx], a0) + __mul24(S1[sx + 1], a1);
+    return (uint32_t)(((__mul24(b0, r0 >> 4) >> 16) + (__mul24(b1, r1 >> 4) >> 16) + 2) >> 2) & 0xffu;
 }
 
 constexpr int kPyrRows = 4;   // destination rows per thread (independent loads in flight)
@@ -258,8 +258,9 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
         uint32_t d[kPyrRows][6];
 #pragma unroll
         for (int r = 0; r < kPyrRows; ++r) {
-            const uint32_t *p0 = reinterpret_cast<const uint32_t *>(sroi + (size_t)yt[r].x * P.pitch + base);
-            const uint32_t *p1 = reinterpret_cast<const uint32_t *>(sroi + (size_t)yt[r].y * P.pitch + base);
+            // rows < 4038 and pitch < 4200 fit the full-rate 24-bit multiplier (a 64-bit mad is quarter rate)
+            const uint32_t *p0 = reinterpret_cast<const uint32_t *>(sroi + (uint32_t)__mul24((int)yt[r].x, P.pitch) + base);
+            const uint32_t *p1 = reinterpret_cast<const uint32_t *>(sroi + (uint32_t)__mul24((int)yt[r].y, P.pitch) + base);
             d[r][0] = p0[0]; d[r][1] = p0[1]; d[r][2] = p0[2];
             d[r][3] = p1[0]; d[r][4] = p1[1]; d[r][5] = p1[2];
         }
@@ -275,9 +276,10 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t q0 = (uint32_t)(w0 >> (8 * rel[k])), q1 = (uint32_t)(w1 >> (8 * rel[k]));
-                const uint32_t h0 = udot2((q0 & 0xffu) | ((q0 & 0xff00u) << 8), alv[k], 0);
-                const uint32_t h1 = udot2((q1 & 0xffu) | ((q1 & 0xff00u) << 8), alv[k], 0);
-                const uint32_t v = (uint32_t)((((b0 * (int)(h0 >> 4)) >> 16) + ((b1 * (int)(h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+                const uint32_t h0 = udot2(__builtin_amdgcn_perm(0u, q0, 0x0c010c00u), alv[k], 0);
+                const uint32_t h1 = udot2(__builtin_amdgcn_perm(0u, q1, 0x0c010c00u), alv[k], 0);
+                // b <= 2048 and h >> 4 < 2^15: the 24-bit multiplier is exact and full rate (v_mul_lo_u32 is quarter rate)
+                const uint32_t v = (uint32_t)(((__mul24(b0, (int)(h0 >> 4)) >> 16) + (__mul24(b1, (int)(h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
                 acc |= v << (8 * k);
             }
             out[r] = acc & vmask;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
     } else {
 #pragma unroll
         for (int r = 0; r < kPyrRows; ++r) {
-            const uint8_t *S0 = sroi + (size_t)yt[r].x * P.pitch, *S1 = sroi + (size_t)yt[r].y * P.pitch;
+            const uint8_t *S0 = sroi + (uint32_t)__mul24((int)yt[r].x, P.pitch), *S1 = sroi + (uint32_t)__mul24((int)yt[r].y, P.pitch);
             uint32_t acc = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
 #pragma unroll
     for (int r = 0; r < kPyrRows; ++r) {
         const int py = rq * kPyrRows + r;
-        if (py < L.prows) *reinterpret_cast<uint32_t *>(dst + (size_t)py * L.pitch + pw * 4) = out[r];
+        if (py < L.prows) *reinterpret_cast<uint32_t *>(dst + (uint32_t)__mul24(py, L.pitch) + pw * 4) = out[r];
     }
 }
 
@@ -396,8 +398,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     int nsurv = 0;
     for (int it0 = 0; it0 < nwork; it0 += 64) {
         const int it = it0 + lane;
-        const int y = (it * magic) >> 20;               // detection row; sub-image row y+3
-        const int g = g_lo + it - y * ngrp;
+        const int y = (int)(__umul24((unsigned)it, (unsigned)magic) >> 20);   // detection row; sub-image row y+3 (24-bit operands)
+        const int g = g_lo + it - __mul24(y, ngrp);
         uint32_t keepm = 0;
         if (it < nwork) {
             const int rb = __mul24(y, SW) + g;              // dword index of (row y, group g)
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
             const int i = min(u * 256 + tid, nin * kBInW - 1);
             const int r = (i * 3641) >> 16, c = i - r * kBInW;   // i / 18 for i < 1152
             const int gy = min(y0 - 3 + r, L.h + kEdge - 1), gx = min(x0 - 4 + 4 * c, gxmax);
-            v[u] = *reinterpret_cast<const uint32_t *>(roi + (ptrdiff_t)gy * L.pitch + gx);
+            v[u] = *reinterpret_cast<const uint32_t *>(roi + (ptrdiff_t)(__mul24(gy, L.pitch) + gx));   // 24-bit operands: full rate
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -994,17 +996,17 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         if ((y & 1) == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                uint32_t acc = udot2(a0[j], w01, udot2(a1[j], w23, udot2(a2[j], w45, (a3[j] & 0xffffu) * (uint32_t)W.w[6])));
+                uint32_t acc = udot2(a0[j], w01, udot2(a1[j], w23, udot2(a2[j], w45, __umul24(a3[j] & 0xffffu, (uint32_t)W.w[6]))));
                 res |= min((acc + 32768u) >> 16, 255u) << (8 * j);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                uint32_t acc = udot2(a1[j], w12, udot2(a2[j], w34, udot2(a3[j], w56, (a0[j] >> 16) * (uint32_t)W.w[0])));
+                uint32_t acc = udot2(a1[j], w12, udot2(a2[j], w34, udot2(a3[j], w56, __umul24(a0[j] >> 16, (uint32_t)W.w[0]))));
                 res |= min((acc + 32768u) >> 16, 255u) << (8 * j);
             }
         }
-        *reinterpret_cast<uint32_t *>(out + (size_t)(y0 + y) * L.pitch + x0 + 4 * g) = res;
+        *reinterpret_cast<uint32_t *>(out + (uint32_t)(__mul24(y0 + y, L.pitch) + x0 + 4 * g)) = res;
     }
 }
 
@@ -1071,22 +1073,22 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
     for (int u = 0; u < 7; ++u) {
         const int idx = min(u * 64 + lane, 37 * 11 - 1);
         const int r = (idx * 5958) >> 16, cdw = idx - r * 11;   // idx / 11 for idx < 407
-        pv[u] = *reinterpret_cast<const uint32_t *>(bb + (size_t)r * L.pitch + 4 * cdw);
+        pv[u] = *reinterpret_cast<const uint32_t *>(bb + (uint32_t)(__mul24(r, L.pitch) + 4 * cdw));   // 24-bit operands: full-rate multiplier
     }
     int m10 = 0, m01 = 0;
     int pix[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int u = (signed char)(duv[i] & 0xff), v = (signed char)(duv[i] >> 8);
-        pix[i] = c[v * L.pitch + u];
+        pix[i] = c[__mul24(v, L.pitch) + u];
     }
 #pragma unroll
     for (int u = 0; u < 7; ++u) patch[min(u * 64 + lane, 37 * 11 - 1)] = pv[u];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int u = (signed char)(duv[i] & 0xff), v = (signed char)(duv[i] >> 8);
-        m10 += u * pix[i];
-        m01 += v * pix[i];
+        m10 += __mul24(u, pix[i]);
+        m01 += __mul24(v, pix[i]);
     }
     m10 = wave_reduce_add(m10);
     m01 = wave_reduce_add(m01);
@@ -1108,8 +1110,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, bsn)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, bsn), __fmul_rn(py1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, bsn)));
-        t0v[j] = cb[r0 * 44 + c0];
-        t1v[j] = cb[r1 * 44 + c1];
+        t0v[j] = cb[__mul24(r0, 44) + c0];
+        t1v[j] = cb[__mul24(r1, 44) + c1];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) bits[j] = __ballot(t0v[j] < t1v[j]);
