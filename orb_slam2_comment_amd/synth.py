@@ -94,3 +94,28 @@ def synth_stereo(seed, W=1241, H=376, n_rect=400, n_disc=200):
 def synth_batch(first_seed, count, W=1241, H=376):
     """uint8 [count, H, W]"""
     return np.stack([synth_frame(first_seed + i, W, H) for i in range(count)])
+
+
+def synth_vocabulary(k=10, L=6, seed=1):
+    """Regular k-ary vocabulary tree with the shape of ORBvoc.txt (k=10, L=6: 1.1 M nodes, 10^6 words) in
+    saveToTextFile (BFS) order, for benchmarks: the real vocabulary is not part of the reference checkout.
+    Children are their parent with a few random bit flips.  Returns (parent, is_leaf, desc, weight), entry i = node i+1,
+    ready for ORBVocabulary.from_arrays."""
+    rng = np.random.default_rng(seed)
+    parent, leaf, desc = [], [], []
+    prev_desc, prev_first = rng.integers(0, 256, (1, 32), dtype=np.uint8), 0
+    nid = 1
+    for depth in range(1, L + 1):
+        n = prev_desc.shape[0] * k
+        d = np.repeat(prev_desc, k, axis=0)
+        for _ in range(max(2, 48 >> depth)):
+            bit = rng.integers(0, 256, n)
+            d[np.arange(n), bit >> 3] ^= (1 << (bit & 7)).astype(np.uint8)
+        parent.append(np.repeat(np.arange(prev_first, prev_first + prev_desc.shape[0], dtype=np.int32), k))
+        leaf.append(np.full(n, depth == L, np.uint8))
+        desc.append(d)
+        prev_desc, prev_first = d, nid
+        nid += n
+    parent, leaf, desc = np.concatenate(parent), np.concatenate(leaf), np.concatenate(desc)
+    weight = np.where(leaf == 1, rng.uniform(0.5, 12.0, len(leaf)), 0.0)
+    return parent, leaf, desc, weight
