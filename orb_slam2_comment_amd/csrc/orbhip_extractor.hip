@@ -425,14 +425,19 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             keepm &= (g == g_lo ? vm_first : 0xfu) & (g == g_hi ? vm_last : 0xfu);
         }
         const uint32_t ent = (uint32_t)((y << 7) | (4 * g));
+        // Ordered append: lane-major, then pixel -- i.e. row-major (y, x), the order the reference emits keypoints in.
+        // Every later compaction is stable, so the final list needs no sorting.  The wave prefix sum of the per-lane
+        // survivor counts (0..4) is three ballots over the bits of the count.
+        const int cnt = __popc(keepm);
+        const unsigned long long p0 = __ballot(cnt & 1), p1 = __ballot(cnt & 2), p2 = __ballot(cnt & 4);
+        int pos = nsurv + lane_prefix(p0) + 2 * lane_prefix(p1) + 4 * lane_prefix(p2);
+        nsurv += __popcll(p0) + 2 * __popcll(p1) + 4 * __popcll(p2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool pre = (keepm >> j) & 1u;
-            const unsigned long long bm = __ballot(pre);
-            // branch-free append: lanes without a survivor write the scratch slot behind the list
-            const int pos = nsurv + lane_prefix(bm);
+            // branch-free: lanes without a survivor write the scratch slot behind the list
             slist[pre ? pos : list_dummy] = (unsigned short)(ent + j);
-            nsurv += __popcll(bm);
+            pos += pre;
         }
     }
     __syncthreads();
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     }
     __syncthreads();
 
-    // ---- 5. threshold fallback + row-major order by rank counting ----
+    // ---- 5. threshold fallback; the list is already row-major, so the rank is a running ballot prefix ----
     const int th = nini > 0 ? G.ini_th : G.min_th;
     uint32_t *out = cell_kp + out_cell * G.slot_cap;
     int total = 0;
@@ -515,18 +520,15 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         const int i = i0 + lane;
         const uint32_t key = i < nfin ? sfinal[i] : 0;
         const bool ok = i < nfin && (int)(key & 0xff) >= th;
-        int rank = 0;
-        for (int j = 0; j < nfin; ++j) {
-            const uint32_t kj = sfinal[j];
-            rank += ((int)(kj & 0xff) >= th) && (kj < key);
-        }
+        const unsigned long long mok = __ballot(ok);
+        const int rank = total + lane_prefix(mok);
         if (ok && rank < G.slot_cap) {
             const int y = (int)(key >> 15), col = (int)((key >> 8) & 127);
             // keypoint relative to (minBorderX, minBorderY): FAST coords + cell offset
             const uint32_t kx = (uint32_t)(col - 4 - a + cd.offx), ky = (uint32_t)(y + 3 + cd.offy);
             out[rank] = kx | (ky << 12) | ((key & 0xffu) << 24);
         }
-        total += __popcll(__ballot(ok));
+        total += __popcll(mok);
     }
     if (lane == 0) cell_cnt[out_cell] = min(total, G.slot_cap);
 }
