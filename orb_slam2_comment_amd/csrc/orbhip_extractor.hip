@@ -372,8 +372,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = min(i0 + u * 64 + lane, total - 1);
-                const int y = (i * F.div_magic) >> 20, wx = min(max(i - y * SW, 1), ndw);
-                v[u] = *reinterpret_cast<const uint32_t *>(roi + (size_t)(cd.y0 + y) * L.pitch + gxb + 4 * (wx - 1));
+                // i < 8192, div_magic < 2^20, rows and pitch < 2^13: everything fits the full-rate 24-bit multiplier
+                const int y = (int)(__umul24((unsigned)i, (unsigned)F.div_magic) >> 20), wx = min(max(i - __mul24(y, SW), 1), ndw);
+                v[u] = *reinterpret_cast<const uint32_t *>(roi + (uint32_t)(__mul24(cd.y0 + y, L.pitch) + gxb + 4 * (wx - 1)));
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) simg[min(i0 + u * 64 + lane, total - 1)] = v[u];
