@@ -879,25 +879,24 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbhip_keypoint *__r
                                                       int *__restrict__ sad, StereoBatch B)
 {
     const int lane = threadIdx.x & 63;
+    size_t pyr_off_l, pyr_off_r;   // this pair's frames inside the two pyramid batches
     {
         const int pair = blockIdx.y, fl = B.l0 + pair * B.ls, fr = B.r0 + pair * B.rs;
+        pyr_off_l = (size_t)fl * B.fb_l; pyr_off_r = (size_t)fr * B.fb_r;
         kl += (size_t)fl * B.cap; dl += (size_t)fl * B.cap * 32;
         kr += (size_t)fr * B.cap; dr += (size_t)fr * B.cap * 32;
         band += (size_t)pair * B.cap;
         uRight += (size_t)pair * B.cap; depth += (size_t)pair * B.cap; sad += (size_t)pair * B.cap;
         if (B.n_l) nl = min(B.n_l[fl], B.cap);
         if (B.n_r) nr = min(B.n_r[fr], B.cap);
-#pragma unroll
-        for (int l = 0; l < ORBHIP_MAX_LEVELS; ++l) {
-            G.left[l] += (size_t)fl * B.fb_l;
-            G.right[l] += (size_t)fr * B.fb_r;
-        }
     }
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (iL >= nl) return;
     if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; sad[iL] = -1; }
     const orbhip_keypoint kpL = kl[iL];
-    const int levelL = kpL.octave;
+    // one keypoint per wavefront: the level is wave-uniform, and saying so keeps the per-level tables of G in scalar
+    // registers (a lane-indexed by-value array would be copied to scratch by every wave)
+    const int levelL = __builtin_amdgcn_readfirstlane(kpL.octave);
     const float vL = kpL.y, uL = kpL.x;
     const int row = (int)vL;
     if (row < 0 || row >= G.nrows) return;
@@ -942,7 +941,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbhip_keypoint *__r
     const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)L), (float)w);
     const float endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, (float)L), (float)w), 1.0f);
     if (iniu < 0 || endu >= (float)G.cols_r[levelL]) return;
-    const uint8_t *imL = G.left[levelL], *imR = G.right[levelL];
+    const uint8_t *imL = G.left[levelL] + pyr_off_l, *imR = G.right[levelL] + pyr_off_r;
     const int stL = G.pitch_l[levelL], stR = G.pitch_r[levelL];
     const int cu = (int)scaleduL, cv = (int)scaledvL, cr = (int)scaleduR0;
     const int cL = imL[(ptrdiff_t)cv * stL + cu];
