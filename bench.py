@@ -76,7 +76,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-gpu", type=int, default=64)
+    ap.add_argument("--frames-per-gpu", type=int, default=128,
+                    help="frames resident in HBM per GPU and step (two 64-frame pipelines by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="skip the secondary extract+match measurement")
     ap.add_argument("--dist-backend", default="nccl",
@@ -297,8 +298,8 @@ def main():
         torch.cuda.synchronize(dev)
         dts = time.perf_counter() - t0
         stereo_info = {"value": round(B // 2 * args.steps / dts, 1), "unit": "stereo pairs/s",
-                       "what": "extract left+right (32 interleaved pairs, one pipeline) + device-resident "
-                               "Frame::ComputeStereoMatches, fx 718.856 bf 386.1448",
+                       "what": "extract left+right (%d interleaved pairs, one pipeline) + device-resident "
+                               "Frame::ComputeStereoMatches, fx 718.856 bf 386.1448" % (B // 2),
                        "ms_per_step": round(dts / args.steps * 1e3, 4),
                        "mean_stereo_matches_per_pair": round(float(s_nm.float().mean().item()), 1)}
         # relocalisation / reference-key-frame chain: extract + Frame::ComputeBoW (ORBvoc-shaped synthetic tree,
@@ -328,14 +329,14 @@ def main():
         torch.cuda.synchronize(dev)
         dtb = time.perf_counter() - t0
         bow_info = {"value": round(B * args.steps / dtb, 1), "unit": "frames/s",
-                    "what": "extract (64 frames, one pipeline) + device-resident Frame::ComputeBoW "
-                            "(ORBVocabulary::transform, synthetic k=10 L=6 tree, levelsup 4)",
+                    "what": "extract (%d frames, one pipeline) + device-resident Frame::ComputeBoW "
+                            "(ORBVocabulary::transform, synthetic k=10 L=6 tree, levelsup 4)" % B,
                     "ms_per_step": round(dtb / args.steps * 1e3, 4),
                     "mean_bow_words_per_frame": round(float(b_n.float().mean().item()), 1)}
         voc.set_stream(0)
         match_info = {"value": round(B * args.steps / dtm, 1), "unit": "frames/s", "stereo": stereo_info, "bow": bow_info,
-                      "what": "extract (64 frames) + device-resident SearchByProjection(CurrentFrame, LastFrame, th=15) "
-                              "for the 32 (2k, 2k+1) pairs of each step; queries built on the GPU",
+                      "what": "extract (%d frames) + device-resident SearchByProjection(CurrentFrame, LastFrame, th=15) "
+                              "for the %d (2k, 2k+1) pairs of each step; queries built on the GPU" % (B, B // 2),
                       "ms_per_step": round(dtm / args.steps * 1e3, 4),
                       "mean_matches_per_pair": round(float(t_nm.float().mean().item()), 1)}
 
