@@ -70,3 +70,28 @@ mout["stereo_n"] = np.int32(n); mout["stereo_ur"] = ur; mout["stereo_depth"] = d
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "match_golden.npz"), **mout)
 print("match golden:", {k: (v.shape if hasattr(v, "shape") and v.shape else int(v)) for k, v in mout.items()},
       os.path.getsize(os.path.join(ROOT, "tests", "golden", "match_golden.npz")))
+
+# ---- vocabulary / BoW fixtures (bow_golden.npz): same frames as the matcher fixtures ----
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import tempfile  # noqa: E402
+from helpers import make_vocabulary, write_vocabulary  # noqa: E402
+
+bout = {}
+voc = make_vocabulary(8, 3, seed=31)
+with tempfile.TemporaryDirectory() as td:
+    ov = O.OracleVocabulary(write_vocabulary(os.path.join(td, "voc.txt"), voc))
+    r1, r2 = ov.transform(d1, 2), ov.transform(d2, 2)     # levelsup 2 of L = 3: 8 FeatureVector nodes
+for key in ("word_id", "word_weight", "node_id", "bow_ids", "bow_vals"):
+    bout["t1_" + key] = r1[key]
+    bout["t2_" + key] = r2[key]
+n, m12 = O.search_by_bow(f1, r1["node_id"], None, f2, r2["node_id"], None, 50, 0.7, True)
+bout["bow_n"] = np.int32(n); bout["bow_m12"] = m12
+sigma2 = (sf * sf).astype(np.float32)
+F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+n, m12 = O.search_for_triangulation(f1, r1["node_id"], None, f2, r2["node_id"], None, F12, 200.0, 150.0, sigma2, False, True)
+bout["tri_n"] = np.int32(n); bout["tri_m12"] = m12
+groups = [d1[i:i + 2 + (i % 9)] for i in range(0, 300, 11)]
+bout["distinct"] = np.array([O.distinctive_descriptor(g) for g in groups], np.int32)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "bow_golden.npz"), **bout)
+print("bow golden:", {k: (v.shape if hasattr(v, "shape") and v.shape else int(v)) for k, v in bout.items()},
+      os.path.getsize(os.path.join(ROOT, "tests", "golden", "bow_golden.npz")))

@@ -295,6 +295,23 @@ def test_oracle_reproduces_committed_golden_vectors(oracle):
     prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
     n, m12, _ = oracle.search_for_initialization(f1, f2, prev, 100, 0.9, True)
     assert n == int(m["init_n"]) and np.array_equal(m12, m["init_m12"])
+    # vocabulary / BoW fixtures on the same two frames
+    from helpers import make_vocabulary, write_vocabulary
+    import tempfile
+    bg = np.load(os.path.join(os.path.dirname(__file__), "golden", "bow_golden.npz"))
+    with tempfile.TemporaryDirectory() as td:
+        ov = oracle.OracleVocabulary(write_vocabulary(os.path.join(td, "voc.txt"), make_vocabulary(8, 3, seed=31)))
+        r1, r2 = ov.transform(d1, 2), ov.transform(d2, 2)
+    for key in ("word_id", "word_weight", "node_id", "bow_ids", "bow_vals"):
+        assert np.array_equal(r1[key], bg["t1_" + key]) and np.array_equal(r2[key], bg["t2_" + key]), key
+    n, m12 = oracle.search_by_bow(f1, r1["node_id"], None, f2, r2["node_id"], None, 50, 0.7, True)
+    assert n == int(bg["bow_n"]) and np.array_equal(m12, bg["bow_m12"])
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    n, m12 = oracle.search_for_triangulation(f1, r1["node_id"], None, f2, r2["node_id"], None, F12, 200.0, 150.0,
+                                             (sf * sf).astype(np.float32), False, True)
+    assert n == int(bg["tri_n"]) and np.array_equal(m12, bg["tri_m12"])
+    groups = [d1[i:i + 2 + (i % 9)] for i in range(0, 300, 11)]
+    assert np.array_equal(np.array([oracle.distinctive_descriptor(g_) for g_ in groups], np.int32), bg["distinct"])
 
 
 def _mini_frame(oracle, xy, desc, angles=None, octaves=None, u_right=None):
