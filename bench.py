@@ -315,11 +315,18 @@ def main():
         b_vals = torch.zeros((B, cap), dtype=torch.float64, device=dev)
         b_n = torch.zeros(B, dtype=torch.int32, device=dev)
 
+        bm = ORBmatcher(0.7, True, device=local_rank)      # Tracking::TrackReferenceKeyFrame, src/Tracking.cc:759
+        bm.set_stream(cur.cuda_stream)
+        b_m12 = torch.zeros((B // 2, cap), dtype=torch.int32, device=dev)
+        b_nm = torch.zeros(B // 2, dtype=torch.int32, device=dev)
+
         def bow_step():
             sext.extract_batch_device(d_simg.data_ptr(), B, H, W, d_kps.data_ptr(), d_desc.data_ptr(), cap,
                                       d_n.data_ptr(), d_st.data_ptr())
             voc.transform_device(B, d_desc.data_ptr(), d_n.data_ptr(), cap, 4, b_word.data_ptr(), b_w.data_ptr(),
                                  b_node.data_ptr(), b_ids.data_ptr(), b_vals.data_ptr(), b_n.data_ptr())
+            side = (d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), b_node.data_ptr())
+            bm.SearchByBoWDevice(B // 2, cap, side, 0, 2, side, 1, 2, b_m12.data_ptr(), b_nm.data_ptr(), 50)
         for _ in range(3):
             bow_step()
         torch.cuda.synchronize(dev)
@@ -330,7 +337,9 @@ def main():
         dtb = time.perf_counter() - t0
         bow_info = {"value": round(B * args.steps / dtb, 1), "unit": "frames/s",
                     "what": "extract (%d frames, one pipeline) + device-resident Frame::ComputeBoW "
-                            "(ORBVocabulary::transform, synthetic k=10 L=6 tree, levelsup 4)" % B,
+                            "(ORBVocabulary::transform, synthetic k=10 L=6 tree, levelsup 4) + device-resident "
+                            "SearchByBoW for the %d (2k, 2k+1) pairs" % (B, B // 2),
+                    "mean_bow_matches_per_pair": round(float(b_nm.float().mean().item()), 1),
                     "ms_per_step": round(dtb / args.steps * 1e3, 4),
                     "mean_bow_words_per_frame": round(float(b_n.float().mean().item()), 1)}
         voc.set_stream(0)

@@ -229,6 +229,19 @@ int orbhip_search_by_bow(orbhip_matcher *m, const orbhip_frame_view *f1, const u
                          const orbhip_frame_view *f2, const uint32_t *node2, const uint8_t *blocked2, int max_dist,
                          float nnratio, int check_ori, int32_t *matches12, int *nmatches);
 
+/* Device-resident, batched orbhip_search_by_bow: pair p matches frame f1_first + p*f1_step of the first set of
+ * arrays (the key-frame side) against frame f2_first + p*f2_step of the second set; both sets are in the layout the
+ * extractor and orbhip_vocabulary_transform_device write (d_kps [frames][cap] orbhip_keypoint, d_desc [frames][cap][32],
+ * d_n [frames] int32, d_node [frames][cap] uint32) and may be the same arrays; d_valid1 / d_blocked2 [frames][cap]
+ * uint8 are optional (null).  Outputs d_matches12 [pairs][cap] int32, d_nmatches [pairs] int32.  One launch on the
+ * matcher's stream, asynchronous; the (node, index) ordering, grouping, matching and rotation cull all happen on
+ * the device.  cap <= 4096. */
+int orbhip_search_by_bow_device(orbhip_matcher *m, int pairs, int cap, const void *d_kps1, const void *d_desc1,
+                                const void *d_n1, const void *d_node1, const void *d_valid1, int f1_first, int f1_step,
+                                const void *d_kps2, const void *d_desc2, const void *d_n2, const void *d_node2,
+                                const void *d_blocked2, int f2_first, int f2_step, int max_dist, float nnratio,
+                                int check_ori, void *d_matches12, void *d_nmatches);
+
 /* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-823).  valid1 / valid2: keypoint has no map point yet
  * (null = all); stereo flags come from the views' u_right (>= 0, null = monocular); f12: the fundamental matrix of
  * LocalMapping::ComputeF12 (src/LocalMapping.cc:536-553) row-major; (ex, ey): epipole of camera 1 in image 2

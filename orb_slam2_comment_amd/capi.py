@@ -69,6 +69,8 @@ SYMBOLS = [
     ("orbhip_search_by_projection_sim3", _i, [_vp, C.POINTER(FrameView), _vp, _vp, _i, _vp, _vp, _pi]),
     ("orbhip_search_best_in_window", _i, [_vp, C.POINTER(FrameView), _vp, _vp, _i, _i, _vp, _vp, _vp]),
     ("orbhip_search_by_bow", _i, [_vp, C.POINTER(FrameView), _vp, _vp, C.POINTER(FrameView), _vp, _vp, _i, _f, _i, _vp, _pi]),
+    ("orbhip_search_by_bow_device", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+                                         _f, _i, _vp, _vp]),
     ("orbhip_search_for_triangulation", _i, [_vp, C.POINTER(FrameView), _vp, _vp, C.POINTER(FrameView), _vp, _vp, _vp, _f,
                                              _f, _vp, _i, _i, _vp, _pi]),
     ("orbhip_distinctive_descriptors", _i, [_vp, _vp, _vp, _i, _vp]),

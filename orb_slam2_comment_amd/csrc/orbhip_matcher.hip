@@ -270,6 +270,165 @@ __global__ __launch_bounds__(256) void k_bow_groups(const NodeGroup *__restrict_
     }
 }
 
+// Device-resident, batched SearchByBoW: one 1024-thread workgroup per (key frame, frame) pair does everything the
+// host path splits between std::sort, k_bow_groups and k_bow_cull: both sides' (node << 32 | index) keys are sorted
+// in LDS (= FeatureVector order), group heads are found on the sorted query keys, the node's candidate range by
+// binary search in the sorted train keys, then the 16 wavefronts take the common nodes round-robin and replay each
+// node's queries in order exactly like k_bow_groups; rotation histogram, cull and count finish in the same launch.
+constexpr int kBowPairMax = 4096;
+struct BowPairShared {
+    unsigned long long qkey[kBowPairMax], tkey[kBowPairMax];
+    int mout[kBowPairMax];
+    unsigned short ghead[kBowPairMax];
+    unsigned char matched[kBowPairMax], bin[kBowPairMax];
+    int hist[HISTO_LENGTH];
+    int nq, nt, ngroups, nmatch;
+};
+struct BowSide {   // one side of the pairs, in the extractor / vocabulary output layout
+    const orbhip_keypoint *kps;
+    const uint8_t *desc;
+    const int *n;
+    const uint32_t *node;
+    const uint8_t *flag;   // query side: valid1 (null = all); train side: blocked2 (null = none)
+    int f0, fs;            // frame index of pair p = f0 + p * fs
+};
+
+__device__ __forceinline__ int lower_bound_u64(const unsigned long long *a, int n, unsigned long long v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(1024) void k_bow_pairs(BowSide Q, BowSide T, int cap, int max_dist, float nnratio,
+                                                    int check_ori, int *__restrict__ matches12, int *__restrict__ nmatches)
+{
+    extern __shared__ unsigned char bow_pair_lds[];
+    BowPairShared &S = *reinterpret_cast<BowPairShared *>(bow_pair_lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = 1024;
+    const int pair = blockIdx.x, fq = Q.f0 + pair * Q.fs, ft = T.f0 + pair * T.fs;
+    const int n1 = min(Q.n[fq], cap), n2 = min(T.n[ft], cap);
+    const orbhip_keypoint *qk = Q.kps + (size_t)fq * cap, *tk = T.kps + (size_t)ft * cap;
+    const uint8_t *qd = Q.desc + (size_t)fq * cap * 32, *td = T.desc + (size_t)ft * cap * 32;
+    const uint32_t *qn = Q.node + (size_t)fq * cap, *tn = T.node + (size_t)ft * cap;
+    const uint8_t *valid1 = Q.flag ? Q.flag + (size_t)fq * cap : nullptr;
+    const uint8_t *blocked2 = T.flag ? T.flag + (size_t)ft * cap : nullptr;
+    matches12 += (size_t)pair * cap;
+    int P = 1024;
+    while (P < max(n1, n2)) P <<= 1;
+    for (int i = tid; i < P; i += NT) {
+        const bool okq = i < n1 && qn[i] != 0xffffffffu && (!valid1 || valid1[i]);
+        S.qkey[i] = okq ? (((unsigned long long)qn[i] << 32) | (unsigned)i) : ~0ull;
+        const bool okt = i < n2 && tn[i] != 0xffffffffu;
+        S.tkey[i] = okt ? (((unsigned long long)tn[i] << 32) | (unsigned)i) : ~0ull;
+        S.mout[i] = -1;
+        S.bin[i] = 0xff;
+    }
+    for (int i = tid; i < cap; i += NT) matches12[i] = -1;
+    if (tid < HISTO_LENGTH) S.hist[tid] = 0;
+    if (tid == 0) { S.nq = 0; S.nt = 0; S.ngroups = 0; S.nmatch = 0; }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += NT) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const unsigned long long a = S.qkey[i], b = S.qkey[l];
+                    if ((a > b) == up) { S.qkey[i] = b; S.qkey[l] = a; }
+                    const unsigned long long c = S.tkey[i], d = S.tkey[l];
+                    if ((c > d) == up) { S.tkey[i] = d; S.tkey[l] = c; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < P; i += NT) {   // sizes of the valid prefixes; group heads of the query side
+        if (S.qkey[i] != ~0ull) {
+            if (i + 1 == P || S.qkey[i + 1] == ~0ull) S.nq = i + 1;
+            if (i == 0 || (uint32_t)(S.qkey[i - 1] >> 32) != (uint32_t)(S.qkey[i] >> 32))
+                S.ghead[atomicAdd(&S.ngroups, 1)] = (unsigned short)i;
+        }
+        if (S.tkey[i] != ~0ull) {
+            if (i + 1 == P || S.tkey[i + 1] == ~0ull) S.nt = i + 1;
+            S.matched[i] = (unsigned char)(blocked2 ? blocked2[(uint32_t)S.tkey[i]] != 0 : 0);
+        }
+    }
+    __syncthreads();
+    const int nq = S.nq, nt = S.nt, ng = S.ngroups;
+    for (int g = wave; g < ng; g += NT / 64) {
+        const int q_begin = S.ghead[g];
+        const unsigned long long nodekey = S.qkey[q_begin] & 0xffffffff00000000ull;
+        const int t_begin = lower_bound_u64(S.tkey, nt, nodekey), t_end = lower_bound_u64(S.tkey, nt, nodekey + (1ull << 32));
+        if (t_end <= t_begin) continue;   // node absent from the frame
+        const int q_end = lower_bound_u64(S.qkey, nq, nodekey + (1ull << 32));
+        const int tc = t_end - t_begin;
+        uint32_t td0[8];
+        const bool have0 = lane < tc;
+        {
+            const uint32_t *tp = reinterpret_cast<const uint32_t *>(td + (size_t)(have0 ? (uint32_t)S.tkey[t_begin + lane] : 0) * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) td0[i] = have0 ? tp[i] : 0u;
+        }
+        bool used0 = have0 ? S.matched[t_begin + lane] != 0 : true;
+        for (int qi = q_begin; qi < q_end; ++qi) {
+            const int idx1 = (int)(uint32_t)S.qkey[qi];
+            uint32_t qdw[8];
+            const uint32_t *qp = reinterpret_cast<const uint32_t *>(qd + (size_t)idx1 * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qdw[i] = qp[i];
+            unsigned long long k1 = ~0ull, k2 = ~0ull;
+            if (!used0) k1 = ((unsigned long long)hamming256(qdw, td0) << 32) | (unsigned)(t_begin + lane);
+            for (int c = t_begin + 64 + lane; c < t_end; c += 64) {
+                if (S.matched[c]) continue;
+                const uint32_t *tp = reinterpret_cast<const uint32_t *>(td + (size_t)(uint32_t)S.tkey[c] * 32);
+                uint32_t t8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t8[i] = tp[i];
+                const unsigned long long k = ((unsigned long long)hamming256(qdw, t8) << 32) | (unsigned)c;
+                if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
+            }
+            const unsigned long long m1 = wave_min_u64(k1);
+            if (m1 == ~0ull) continue;
+            const unsigned long long m2 = wave_min_u64(k1 == m1 ? k2 : k1);
+            const int bestDist1 = (int)(m1 >> 32), bestDist2 = m2 == ~0ull ? 256 : (int)(m2 >> 32);
+            if (bestDist1 <= max_dist && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
+                const int slot = (int)(uint32_t)m1;
+                if (((slot - t_begin) & 63) == lane) {
+                    S.matched[slot] = 1;
+                    if (slot - t_begin < 64) used0 = true;
+                }
+                if (lane == 0) {
+                    const int idx2 = (int)(uint32_t)S.tkey[slot];
+                    S.mout[qi] = idx2;
+                    if (check_ori) {
+                        const int b = rot_bin(qk[idx1].angle, tk[idx2].angle);
+                        atomicAdd(&S.hist[b], 1);
+                        S.bin[qi] = (unsigned char)b;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    if (check_ori) three_maxima(S.hist, ind1, ind2, ind3);
+    int cnt = 0;
+    for (int p = tid; p < nq; p += NT) {
+        const int mval = S.mout[p];
+        if (mval < 0) continue;
+        const int b = S.bin[p];
+        if (check_ori && b != ind1 && b != ind2 && b != ind3) continue;
+        matches12[(uint32_t)S.qkey[p]] = mval;
+        ++cnt;
+    }
+    if (cnt) atomicAdd(&S.nmatch, cnt);
+    __syncthreads();
+    if (tid == 0) nmatches[pair] = S.nmatch;
+}
+
 // rotation-consistency cull + count (ORBmatcher.cc:271-285 / :633-651); one workgroup
 __global__ __launch_bounds__(1024) void k_bow_cull(int nq, int check_ori, const int *__restrict__ hist,
                                                    const uint8_t *__restrict__ bin, int *__restrict__ match, int *out_n)
@@ -1067,7 +1226,7 @@ struct orbhip_matcher {
     // grow-only device scratch
     void *buf[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bool lds_attr_set = false;
+    bool lds_attr_set = false, bow_attr_set = false;
     // pinned host staging: all inputs of a call travel in one DMA, all outputs in one
     uint8_t *h_stage = nullptr; size_t h_stage_bytes = 0;
     uint8_t *h_out = nullptr; size_t h_out_bytes = 0;
@@ -1537,6 +1696,36 @@ int orbhip_search_by_bow(orbhip_matcher *m, const orbhip_frame_view *f1, const u
     if ((f1->n > 0 && (!node1 || !f1->keys || !f1->desc)) || (f2->n > 0 && (!node2 || !f2->keys || !f2->desc)))
         return ORBHIP_E_ARG;
     return run_bow(m, f1, node1, valid1, f2, node2, blocked2, max_dist, nnratio, check_ori, matches12, nmatches);
+}
+
+int orbhip_search_by_bow_device(orbhip_matcher *m, int pairs, int cap, const void *d_kps1, const void *d_desc1,
+                                const void *d_n1, const void *d_node1, const void *d_valid1, int f1_first, int f1_step,
+                                const void *d_kps2, const void *d_desc2, const void *d_n2, const void *d_node2,
+                                const void *d_blocked2, int f2_first, int f2_step, int max_dist, float nnratio,
+                                int check_ori, void *d_matches12, void *d_nmatches)
+{
+    if (!m || pairs < 0 || cap < 1 || !d_kps1 || !d_desc1 || !d_n1 || !d_node1 || !d_kps2 || !d_desc2 || !d_n2 || !d_node2 ||
+        !d_matches12 || !d_nmatches || f1_first < 0 || f2_first < 0 || f1_step < 0 || f2_step < 0)
+        return ORBHIP_E_ARG;
+    if (cap > kBowPairMax) {
+        set_error("search_by_bow_device: capacity %d exceeds the LDS-resident limit %d", cap, kBowPairMax);
+        return ORBHIP_E_CAPACITY;
+    }
+    if (pairs == 0) return ORBHIP_OK;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    if (!m->bow_attr_set) {
+        ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_pairs),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BowPairShared)));
+        m->bow_attr_set = true;
+    }
+    const BowSide Q = {(const orbhip_keypoint *)d_kps1, (const uint8_t *)d_desc1, (const int *)d_n1, (const uint32_t *)d_node1,
+                       (const uint8_t *)d_valid1, f1_first, f1_step};
+    const BowSide T = {(const orbhip_keypoint *)d_kps2, (const uint8_t *)d_desc2, (const int *)d_n2, (const uint32_t *)d_node2,
+                       (const uint8_t *)d_blocked2, f2_first, f2_step};
+    hipLaunchKernelGGL(k_bow_pairs, dim3(pairs), dim3(1024), sizeof(BowPairShared), m->stream, Q, T, cap, max_dist, nnratio,
+                       check_ori, (int *)d_matches12, (int *)d_nmatches);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    return ORBHIP_OK;
 }
 
 int orbhip_search_for_triangulation(orbhip_matcher *m, const orbhip_frame_view *f1, const uint32_t *node1,

@@ -173,6 +173,16 @@ class ORBmatcher:
                                              C.byref(nm)), "orbhip_search_by_bow")
         return nm.value, m12[:F1.N].copy()
 
+    def SearchByBoWDevice(self, pairs, cap, side1, f1_first, f1_step, side2, f2_first, f2_step, d_matches12, d_nmatches,
+                          max_dist=50, d_valid1=0, d_blocked2=0):
+        """Device-resident, batched SearchByBoW.  side1 / side2 = (d_kps, d_desc, d_n, d_node) device pointers (ints)
+        in the extractor / vocabulary batch layout; asynchronous on the matcher's stream."""
+        check(self._lib.orbhip_search_by_bow_device(self._h, pairs, cap, side1[0], side1[1], side1[2], side1[3], d_valid1,
+                                                    f1_first, f1_step, side2[0], side2[1], side2[2], side2[3], d_blocked2,
+                                                    f2_first, f2_step, int(max_dist), self.mfNNratio,
+                                                    int(self.mbCheckOrientation), d_matches12, d_nmatches),
+              "orbhip_search_by_bow_device")
+
     def SearchForTriangulation(self, F1, node1, valid1, F2, node2, valid2, F12, epipole, level_sigma2, bOnlyStereo=False):
         """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-823).  Returns (nmatches, matches12[n1]); the
         reference's vMatchedPairs are the (i, matches12[i]) with matches12[i] >= 0."""

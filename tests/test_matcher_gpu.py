@@ -582,3 +582,61 @@ def test_distinctive_descriptors(env):
     with pytest.raises(pkg.OrbHipError):
         m.ComputeDistinctiveDescriptors([np.zeros((2049, 32), np.uint8)])
     assert len(m.ComputeDistinctiveDescriptors([])) == 0
+
+
+def test_search_by_bow_device_matches_host_api(env):
+    """orbhip_search_by_bow_device (sorting, grouping, matching and cull in one launch) against the host-pointer API
+    and the oracle, with valid / blocked flags, few crowded nodes (candidate lists > 64) and an empty pair."""
+    import torch
+    pkg, M, O = env
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda:0")
+    cap, frames = 1400, 4
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    base = rng.integers(0, 256, (60, 32), dtype=np.uint8)
+    ns = [1300, 1400, 0, 900]
+    kps = np.zeros((frames, cap), pkg.KP_DTYPE)
+    desc = np.zeros((frames, cap, 32), np.uint8)
+    node = np.full((frames, cap), 0xFFFFFFFF, np.uint32)
+    valid = np.zeros((frames, cap), np.uint8)
+    blocked = np.zeros((frames, cap), np.uint8)
+    for f, n in enumerate(ns):
+        d = base[rng.integers(0, len(base), n)].copy()
+        d ^= (rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8)
+              & rng.integers(0, 256, (n, 32), dtype=np.uint8)) * (rng.random((n, 1)) < 0.7)
+        desc[f, :n] = d
+        kps[f, :n]["x"] = rng.uniform(0, 640, n); kps[f, :n]["y"] = rng.uniform(0, 480, n)
+        kps[f, :n]["angle"] = rng.uniform(0, 360, n).astype(np.float32); kps[f, :n]["octave"] = rng.integers(0, 8, n)
+        node[f, :n] = rng.integers(0, 9, n) * 1000 + 5
+        node[f, :n][rng.random(n) < 0.05] = 0xFFFFFFFF
+        valid[f, :n] = rng.random(n) < 0.8
+        blocked[f, :n] = rng.random(n) < 0.2
+    t = {k: torch.from_numpy(v.view(np.uint8) if v.dtype == pkg.KP_DTYPE else v).to(dev)
+         for k, v in dict(kps=kps, desc=desc, valid=valid, blocked=blocked).items()}
+    t_node = torch.from_numpy(node.view(np.int32)).to(dev)
+    t_n = torch.tensor(ns, dtype=torch.int32, device=dev)
+    img = np.zeros((480, 640), np.uint8)
+    for nnratio, ori, max_dist, use_flags in ((0.75, True, 50, True), (0.9, False, 100, False)):
+        m = pkg.ORBmatcher(nnratio, ori)
+        pairs = 3                                   # (0,1), (1,2) with an empty frame, (2,3) empty key-frame side
+        d_m12 = torch.full((pairs, cap), -5, dtype=torch.int32, device=dev)
+        d_nm = torch.full((pairs,), -5, dtype=torch.int32, device=dev)
+        side = (t["kps"].data_ptr(), t["desc"].data_ptr(), t_n.data_ptr(), t_node.data_ptr())
+        m.SearchByBoWDevice(pairs, cap, side, 0, 1, side, 1, 1, d_m12.data_ptr(), d_nm.data_ptr(), max_dist,
+                            t["valid"].data_ptr() if use_flags else 0, t["blocked"].data_ptr() if use_flags else 0)
+        m.sync()
+        got, gn = d_m12.cpu().numpy(), d_nm.cpu().numpy()
+        for p in range(pairs):
+            f1, f2 = p, p + 1
+            g1, o1, keep1 = _views(pkg, O, img, kps[f1, :ns[f1]], desc[f1, :ns[f1]], sf)
+            g2, o2, keep2 = _views(pkg, O, img, kps[f2, :ns[f2]], desc[f2, :ns[f2]], sf)
+            v1 = valid[f1, :ns[f1]] if use_flags else None
+            b2 = blocked[f2, :ns[f2]] if use_flags else None
+            on, om12 = O.search_by_bow(o1, node[f1, :ns[f1]], v1, o2, node[f2, :ns[f2]], b2, max_dist, nnratio, ori)
+            assert gn[p] == on and np.array_equal(got[p, :ns[f1]], om12), (p, gn[p], on)
+            assert (got[p, ns[f1]:] == -1).all()
+            hn, hm12 = m.SearchByBoW(g1, node[f1, :ns[f1]], v1, g2, node[f2, :ns[f2]], b2, max_dist)
+            assert hn == on and np.array_equal(hm12, om12)
+        assert gn[0] > 50
+    with pytest.raises(pkg.OrbHipError):
+        m.SearchByBoWDevice(1, 4097, side, 0, 1, side, 1, 1, d_m12.data_ptr(), d_nm.data_ptr())

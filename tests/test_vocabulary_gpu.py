@@ -125,8 +125,16 @@ def test_device_batch_and_bow_matching_chain(env, tmp_path):
     d_nb = torch.zeros(B, dtype=torch.int32, device=dev)
     gv.transform_device(B, d_desc.data_ptr(), d_n.data_ptr(), cap, 4, d_word.data_ptr(), d_w.data_ptr(), d_node.data_ptr(),
                         d_bid.data_ptr(), d_bv.data_ptr(), d_nb.data_ptr())
+    # ... and the BoW-guided matching of (frame 0 -> 1) and (frame 1 -> 2), still in the same queue
+    mdev = pkg.ORBmatcher(0.7, True)
+    mdev.set_stream(ext.stream())
+    d_m12 = torch.full((2, cap), -7, dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(2, dtype=torch.int32, device=dev)
+    side = (d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), d_node.data_ptr())
+    mdev.SearchByBoWDevice(2, cap, side, 0, 1, side, 1, 1, d_m12.data_ptr(), d_nm.data_ptr(), 50)
     gv.sync()
     gv.set_stream(0)
+    mdev.set_stream(0)
     n = d_n.cpu().numpy()
     nb = d_nb.cpu().numpy()
     frames = []
@@ -150,6 +158,13 @@ def test_device_batch_and_bow_matching_chain(env, tmp_path):
     on, om12 = O.search_by_bow(o1, n1, None, o2, n2, None, 50, 0.7, True)
     assert nm == on and np.array_equal(m12, om12)
     assert nm > 100                       # shifted copy of the same scene: most features land in the same node
+    # device-resident batched form: pair 0 = frames (0, 1), pair 1 = frames (1, 2)
+    assert int(d_nm[0]) == on and np.array_equal(d_m12[0, :len(k1)].cpu().numpy(), om12)
+    assert (d_m12[0, len(k1):].cpu().numpy() == -1).all()
+    (k3, d3, n3) = frames[2]
+    g3, o3, keep3 = _views(pkg, O, imgs[2], k3, d3, sf)
+    on2, om12b = O.search_by_bow(o2, n2, None, o3, n3, None, 50, 0.7, True)
+    assert int(d_nm[1]) == on2 and np.array_equal(d_m12[1, :len(k2)].cpu().numpy(), om12b)
     fv = pkg.ORBVocabulary.feature_vector(n1)
     assert sum(len(v) for v in fv.values()) == int((n1 != pkg.capi.NO_NODE).sum())
 
