@@ -1149,14 +1149,14 @@ static int cv_round(double v) { return (int)lrint(v); }
 
 static void free_geometry(orbhip_extractor *e)
 {
-    hipFree(e->d_cells); hipFree(e->d_tiles); hipFree(e->d_tabs);
+    (void)hipFree(e->d_cells); (void)hipFree(e->d_tiles); (void)hipFree(e->d_tabs);
     e->d_cells = nullptr; e->d_tiles = nullptr; e->d_tabs = nullptr;
     e->bound = false;
 }
 static void free_batch(orbhip_extractor *e)
 {
-    hipFree(e->d_pyr); hipFree(e->d_blur); hipFree(e->d_cell_cnt); hipFree(e->d_cell_kp);
-    hipFree(e->d_keys); hipFree(e->d_knode); hipFree(e->d_sel); hipFree(e->d_sel_cnt); hipFree(e->d_status);
+    (void)hipFree(e->d_pyr); (void)hipFree(e->d_blur); (void)hipFree(e->d_cell_cnt); (void)hipFree(e->d_cell_kp);
+    (void)hipFree(e->d_keys); (void)hipFree(e->d_knode); (void)hipFree(e->d_sel); (void)hipFree(e->d_sel_cnt); (void)hipFree(e->d_status);
     e->d_pyr = e->d_blur = nullptr; e->d_cell_cnt = nullptr; e->d_cell_kp = nullptr; e->d_keys = nullptr;
     e->d_knode = nullptr; e->d_sel = nullptr; e->d_sel_cnt = nullptr; e->d_status = nullptr;
     e->batch_cap = 0;
@@ -1353,7 +1353,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     hipEvent_t *ev = prof ? &e->ev[(size_t)(e->prof_calls % orbhip_extractor::kProfRing) * orbhip_extractor::kProfEv] : nullptr;
     int *status = d_status ? d_status : e->d_status;
     hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
-    if (prof) hipEventRecord(ev[0], s);
+    if (prof) (void)hipEventRecord(ev[0], s);
     {
         const LevelGeom &L = G.lv[0];
         int n = (L.pitch >> 4) * L.prows;
@@ -1365,27 +1365,27 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
             hipLaunchKernelGGL(k_pyr_resize, dim3((nl + 255) / 256, batch), dim3(256), 0, s, e->d_pyr, G, l, e->d_tabs);
         }
     }
-    if (prof) hipEventRecord(ev[1], s);
+    if (prof) (void)hipEventRecord(ev[1], s);
     if (G.ncells_total > 0)
         hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, batch), dim3(64), (size_t)e->fast_lds_bytes, s, e->d_pyr, G,
                            e->d_cells, e->d_cell_cnt, e->d_cell_kp, e->fast_lds);
-    if (prof) hipEventRecord(ev[2], s);
+    if (prof) (void)hipEventRecord(ev[2], s);
     if (e->octree_maxn == 512)
         hipLaunchKernelGGL(k_octree<512>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
                            e->d_keys, e->d_knode, e->d_sel, e->d_sel_cnt, status);
     else
         hipLaunchKernelGGL(k_octree<2048>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
                            e->d_keys, e->d_knode, e->d_sel, e->d_sel_cnt, status);
-    if (prof) hipEventRecord(ev[3], s);
+    if (prof) (void)hipEventRecord(ev[3], s);
     // The blur only needs the pyramid.  Forking it onto a second stream beside FAST/octree was measured: it buys
     // nothing once two pipelines (handles) run concurrently and makes throughput depend on how the runtime maps
     // streams to hardware queues (122 k vs 136 k frames/s run to run), so it stays in order on this stream.
     hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, e->d_pyr, e->d_blur, G,
                        e->d_tiles, e->blurw);
-    if (prof) hipEventRecord(ev[4], s);
+    if (prof) (void)hipEventRecord(ev[4], s);
     hipLaunchKernelGGL(k_orient_describe, dim3((G.kp_cap_total + 3) / 4, batch), dim3(256), 0, s, e->d_pyr, e->d_blur,
                        G, e->d_sel, e->d_sel_cnt, e->d_disc, e->d_pattern, d_kps, d_desc, cap, d_n, status);
-    if (prof) { hipEventRecord(ev[5], s); e->prof_calls++; }
+    if (prof) { (void)hipEventRecord(ev[5], s); e->prof_calls++; }
     e->last_batch = batch;
     ORBHIP_HIP_CHECK(hipGetLastError());
     return ORBHIP_OK;
@@ -1458,8 +1458,10 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
     if (hipMalloc(&e->d_disc, sizeof(DiscTab)) != hipSuccess || hipMalloc(&e->d_pattern, 256 * sizeof(int)) != hipSuccess) {
         set_error("hipMalloc failed"); orbhip_extractor_destroy(e); return ORBHIP_E_HIP;
     }
-    hipMemcpy(e->d_disc, &dt, sizeof(dt), hipMemcpyHostToDevice);
-    hipMemcpy(e->d_pattern, orbhip_rbrief_pattern, 1024, hipMemcpyHostToDevice);
+    if (hipMemcpy(e->d_disc, &dt, sizeof(dt), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->d_pattern, orbhip_rbrief_pattern, 1024, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("upload of the orientation / rBRIEF tables failed"); orbhip_extractor_destroy(e); return ORBHIP_E_HIP;
+    }
     *out = e;
     return ORBHIP_OK;
 }
@@ -1467,15 +1469,15 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
 void orbhip_extractor_destroy(orbhip_extractor *e)
 {
     if (!e) return;
-    hipSetDevice(e->device);
-    if (e->stream) hipStreamSynchronize(e->stream);
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_geometry(e);
     free_batch(e);
-    hipFree(e->d_disc); hipFree(e->d_pattern); hipFree(e->d_img); hipFree(e->d_okp); hipFree(e->d_odesc); hipFree(e->d_on);
-    if (e->h_in) hipHostFree(e->h_in);
-    if (e->h_out) hipHostFree(e->h_out);
-    for (hipEvent_t v : e->ev) hipEventDestroy(v);
-    if (e->own_stream) hipStreamDestroy(e->own_stream);
+    (void)hipFree(e->d_disc); (void)hipFree(e->d_pattern); (void)hipFree(e->d_img); (void)hipFree(e->d_okp); (void)hipFree(e->d_odesc); (void)hipFree(e->d_on);
+    if (e->h_in) (void)hipHostFree(e->h_in);
+    if (e->h_out) (void)hipHostFree(e->h_out);
+    for (hipEvent_t v : e->ev) (void)hipEventDestroy(v);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
 
@@ -1546,12 +1548,12 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
     // staging buffers
     const size_t img_bytes = (size_t)batch * rows * cols;
     if (img_bytes > e->d_img_bytes) {
-        hipFree(e->d_img); e->d_img = nullptr; e->d_img_bytes = 0;
+        (void)hipFree(e->d_img); e->d_img = nullptr; e->d_img_bytes = 0;
         ORBHIP_HIP_CHECK(hipMalloc(&e->d_img, img_bytes));
         e->d_img_bytes = img_bytes;
     }
     if ((size_t)cap * batch > e->out_slots || batch > e->out_batch) {
-        hipFree(e->d_okp); hipFree(e->d_odesc); hipFree(e->d_on);
+        (void)hipFree(e->d_okp); (void)hipFree(e->d_odesc); (void)hipFree(e->d_on);
         e->d_okp = nullptr; e->d_odesc = nullptr; e->d_on = nullptr;
         e->out_slots = 0; e->out_batch = 0;
         const size_t slots = std::max((size_t)cap * batch, e->out_slots);
@@ -1563,14 +1565,14 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
     }
     // host -> pinned staging (row copies on the CPU) -> one DMA
     if (img_bytes > e->h_in_bytes) {
-        if (e->h_in) hipHostFree(e->h_in);
+        if (e->h_in) (void)hipHostFree(e->h_in);
         e->h_in = nullptr; e->h_in_bytes = 0;
         ORBHIP_HIP_CHECK(hipHostMalloc((void **)&e->h_in, img_bytes, hipHostMallocDefault));
         e->h_in_bytes = img_bytes;
     }
     const size_t out_bytes = (size_t)batch * (2 * sizeof(int) + (size_t)cap * (sizeof(orbhip_keypoint) + 32));
     if (out_bytes > e->h_out_bytes) {
-        if (e->h_out) hipHostFree(e->h_out);
+        if (e->h_out) (void)hipHostFree(e->h_out);
         e->h_out = nullptr; e->h_out_bytes = 0;
         ORBHIP_HIP_CHECK(hipHostMalloc((void **)&e->h_out, out_bytes, hipHostMallocDefault));
         e->h_out_bytes = out_bytes;

@@ -1251,7 +1251,7 @@ static int scratch(orbhip_matcher *m, int slot, size_t bytes, void **out)
     if (bytes < 256) bytes = 256;
     if (bytes > m->cap[slot]) {
         ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
-        hipFree(m->buf[slot]);
+        (void)hipFree(m->buf[slot]);
         m->buf[slot] = nullptr; m->cap[slot] = 0;
         ORBHIP_HIP_CHECK(hipMalloc(&m->buf[slot], bytes));
         m->cap[slot] = bytes;
@@ -1267,7 +1267,7 @@ static int stage_begin(orbhip_matcher *m, size_t total, Stage *st)
     total = al256(total) + 256;
     ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));   // previous call's staging is free
     if (total > m->h_stage_bytes) {
-        if (m->h_stage) hipHostFree(m->h_stage);
+        if (m->h_stage) (void)hipHostFree(m->h_stage);
         m->h_stage = nullptr; m->h_stage_bytes = 0;
         ORBHIP_HIP_CHECK(hipHostMalloc((void **)&m->h_stage, total, hipHostMallocDefault));
         m->h_stage_bytes = total;
@@ -1286,7 +1286,7 @@ static int stage_commit(orbhip_matcher *m, Stage *st)
 static int out_buffer(orbhip_matcher *m, size_t bytes, uint8_t **h)
 {
     if (bytes > m->h_out_bytes) {
-        if (m->h_out) hipHostFree(m->h_out);
+        if (m->h_out) (void)hipHostFree(m->h_out);
         m->h_out = nullptr; m->h_out_bytes = 0;
         ORBHIP_HIP_CHECK(hipHostMalloc((void **)&m->h_out, bytes, hipHostMallocDefault));
         m->h_out_bytes = bytes;
@@ -1573,12 +1573,12 @@ int orbhip_matcher_create(int device, orbhip_matcher **out)
 void orbhip_matcher_destroy(orbhip_matcher *m)
 {
     if (!m) return;
-    hipSetDevice(m->device);
-    if (m->stream) hipStreamSynchronize(m->stream);
-    for (int i = 0; i < 12; ++i) hipFree(m->buf[i]);
-    if (m->h_stage) hipHostFree(m->h_stage);
-    if (m->h_out) hipHostFree(m->h_out);
-    if (m->own_stream) hipStreamDestroy(m->own_stream);
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (int i = 0; i < 12; ++i) (void)hipFree(m->buf[i]);
+    if (m->h_stage) (void)hipHostFree(m->h_stage);
+    if (m->h_out) (void)hipHostFree(m->h_out);
+    if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
 }
 
