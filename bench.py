@@ -149,29 +149,38 @@ def main():
         streams.append(st)
     ext = exts[0]
     cap = ext.capacity(H, W)
-    d_kps = torch.zeros((B, cap, 7), dtype=torch.int32, device=dev)
-    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    # one flat allocation per output set: {KeyPoint[B][cap] | desc[B][cap][32] | count[B]} are views of it, so the
+    # multi-GPU exchange is ONE gather of one contiguous buffer per step
+    nb_k, nb_d = B * cap * 28, B * cap * 32
+    off_d = (nb_k + 255) & ~255                      # every view starts 256-byte aligned
+    off_n = (off_d + nb_d + 255) & ~255
+    flat_bytes = off_n + B * 4
+
+    def out_set():
+        flat = torch.zeros(flat_bytes, dtype=torch.uint8, device=dev)
+        return (flat[:nb_k].view(torch.int32).view(B, cap, 7), flat[off_d:off_d + nb_d].view(B, cap, 32),
+                flat[off_n:].view(torch.int32), torch.zeros(B, dtype=torch.int32, device=dev), flat)
+
+    d_kps, d_desc, d_n, d_st, d_flat = out_set()
     torch.cuda.synchronize(dev)
 
     # multi-rank: outputs are double-buffered and the RCCL gather of step k runs on its own stream beside the
     # extraction of step k+1; rank 0 gathers into preallocated rank-major buffers (no per-step allocation)
     nbuf = 2 if multi and not rehearsal else 1
-    obuf = [(d_kps, d_desc, d_n, d_st)]
+    obuf = [(d_kps, d_desc, d_n, d_st, d_flat)]
     for _ in range(nbuf - 1):
-        obuf.append((torch.zeros_like(d_kps), torch.zeros_like(d_desc), torch.zeros_like(d_n), torch.zeros_like(d_st)))
+        obuf.append(out_set())
     gstream = torch.cuda.Stream(dev) if nbuf == 2 else None
     gdone = [None, None]
     gout = None
     if nbuf == 2 and rank == 0:
-        gout = [torch.zeros((world,) + tuple(t.shape), dtype=t.dtype, device=dev) for t in (d_kps, d_desc, d_n)]
+        gout = [torch.zeros((world, flat_bytes), dtype=torch.uint8, device=dev)]   # rank-major, same carve-up per rank
     stepno = [0]
 
     def step():
         k = stepno[0] % nbuf
         stepno[0] += 1
-        ok, od, on, ost = obuf[k]
+        ok, od, on, ost, oflat = obuf[k]
         if gdone[k] is not None:                 # the gather that last read this buffer must be finished
             for st in streams:
                 st.wait_event(gdone[k])
@@ -186,7 +195,7 @@ def main():
             for st in streams:
                 gstream.wait_stream(st)
             with torch.cuda.stream(gstream):
-                out = gather_into(gout, (ok, od, on))
+                out = gather_into(gout, (oflat,))
                 gdone[k] = gstream.record_event()
             return out
         return None
