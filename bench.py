@@ -368,13 +368,20 @@ def main():
             kern = "fast"                           # rocprofv3 --stats: k_fast_cells has the largest total time
         algo = ALGO_BYTES[kern] * Bh                # frames per launch of one handle
         achieved = algo / (stage[kern] * 1e-6) / 1e9
-        traffic = None
+        traffic, valu = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = round(json.load(open(tpath))[kern]["hbm_bytes_per_frame"] * Bh)
+                pm = json.load(open(tpath))[kern]
+                traffic = round(pm["hbm_bytes_per_frame"] * Bh)
+                if "valu_issue_us_per_frame" in pm:
+                    # the kernel is priced against HBM as the contract asks, but what bounds it is VALU issue:
+                    # PMC instruction count x 4 cycles / (1024 SIMDs x 2.4 GHz) against the measured launch time
+                    vi = pm["valu_issue_us_per_frame"] * Bh
+                    valu = {"insts_per_launch": pm["valu_insts_per_frame"] * Bh, "issue_us_per_launch": round(vi, 1),
+                            "frac_of_launch": round(vi / stage[kern], 3)}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         try:
             metric_name = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
@@ -395,7 +402,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": {"pyramid": "k_pyr_level0+k_pyr_resize(x7)", "fast": "k_fast_cells",
                                                     "blur": "k_blur", "describe": "k_orient_describe"}[kern],
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "valu_issue": valu,
                          "algorithmic_bytes_per_launch": algo,
                          "avg_launch_us": round(stage[kern], 2),
                          "stage_us": {k: round(v, 2) for k, v in stage.items()},

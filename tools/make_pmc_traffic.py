@@ -23,5 +23,12 @@ out = {
                 "hbm_bytes_per_frame": round((hbm("orbhip::k_pyr_level0") + 7 * hbm("orbhip::k_pyr_resize")) / frames)},
     "octree": {"kernel": "k_octree", "hbm_bytes_per_frame": round(hbm([k for k in d if "k_octree" in k][0]) / frames)},
 }
+# VALU issue load of every stage ("report VALU utilisation alongside"): one VALU instruction occupies its
+# SIMD for 4 cycles (wave64 on a 16-lane SIMD); 256 CUs x 4 SIMDs, 2.4 GHz
+for stage, key in (("fast", "orbhip::k_fast_cells"), ("blur", "orbhip::k_blur"), ("describe", "orbhip::k_orient_describe")):
+    v = d[key]
+    if "SQ_INSTS_VALU" in v:
+        out[stage]["valu_insts_per_frame"] = round(v["SQ_INSTS_VALU"] / frames)
+        out[stage]["valu_issue_us_per_frame"] = round(v["SQ_INSTS_VALU"] / frames * 4 / 1024 / 2.4e3, 4)
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
