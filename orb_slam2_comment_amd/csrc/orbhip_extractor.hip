@@ -144,50 +144,60 @@ __device__ __forceinline__ void det_sincos(float angle_rad, float *c, float *s)
 // One thread produces 4 consecutive bytes of the padded destination row
 // (one dword store); border pixels recompute the reflected interior pixel.
 // ---------------------------------------------------------------------------
+constexpr int kL0Q = 2;   // 16-byte groups per thread of k_pyr_level0
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ images, int stride,
                                                     size_t frame_stride, uint8_t *__restrict__ pyr,
                                                     PyrGeom G)
 {
-    // one thread = 16 bytes of the padded destination row (one uint4 store).  Interior groups read their 16
+    // one thread = kL0Q x 16 bytes of the padded destination row (uint4 stores).  Interior groups read their 16
     // source bytes as five aligned dwords re-aligned with v_alignbyte_b32 (image rows have an odd stride);
     // groups touching the REFLECT_101 frame or the row ends go byte by byte.
     const LevelGeom L = G.lv[0];
-    const int quads = L.pitch >> 4;
+    const int quads = L.pitch >> 4, units = (quads + kL0Q - 1) / kL0Q;
     int bx, fr;
     xcd_remap(bx, fr);
     const int idx = bx * 256 + threadIdx.x;
-    if (idx >= quads * L.prows) return;
-    const int py = idx / quads, pq = idx - py * quads;
+    if (idx >= units * L.prows) return;
+    const int py = idx / units, pu = idx - py * units;
     const uint8_t *src = images + (size_t)fr * frame_stride;
     uint8_t *dst = pyr + (size_t)fr * G.frame_bytes + L.plane_off;
     const int sy = reflect101(py - kEdge, L.h);
     const uint8_t *srow = src + (size_t)sy * stride;
-    const int x0 = pq * 16 - kPadL;
-    uint32_t out[4];
-    if (x0 >= 16 && x0 + 19 < L.w) {
-        const uint8_t *p = srow + x0;
-        const unsigned al = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(p - al);
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-        out[0] = __builtin_amdgcn_alignbyte(d1, d0, al);
-        out[1] = __builtin_amdgcn_alignbyte(d2, d1, al);
-        out[2] = __builtin_amdgcn_alignbyte(d3, d2, al);
-        out[3] = __builtin_amdgcn_alignbyte(d4, d3, al);
-    } else {
+    uint8_t *drow = dst + (size_t)py * L.pitch;
+    uint32_t out[kL0Q][4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            uint32_t acc = 0;
+    for (int q = 0; q < kL0Q; ++q) {
+        const int pq = min(pu * kL0Q + q, quads - 1);   // the tail repeats the last group (same bytes stored twice)
+        const int x0 = pq * 16 - kPadL;
+        if (x0 >= 16 && x0 + 19 < L.w) {
+            const uint8_t *p = srow + x0;
+            const unsigned al = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(p - al);
+            const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+            out[q][0] = __builtin_amdgcn_alignbyte(d1, d0, al);
+            out[q][1] = __builtin_amdgcn_alignbyte(d2, d1, al);
+            out[q][2] = __builtin_amdgcn_alignbyte(d3, d2, al);
+            out[q][3] = __builtin_amdgcn_alignbyte(d4, d3, al);
+        } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int x = x0 + 4 * w + k;
-                uint32_t v = 0;
-                if (x >= -kEdge && x < L.w + kEdge) v = srow[reflect101(x, L.w)];
-                acc |= v << (8 * k);
+            for (int w = 0; w < 4; ++w) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x = x0 + 4 * w + k;
+                    uint32_t v = 0;
+                    if (x >= -kEdge && x < L.w + kEdge) v = srow[reflect101(x, L.w)];
+                    acc |= v << (8 * k);
+                }
+                out[q][w] = acc;
             }
-            out[w] = acc;
         }
     }
-    *reinterpret_cast<uint4 *>(dst + (size_t)py * L.pitch + pq * 16) = make_uint4(out[0], out[1], out[2], out[3]);
+#pragma unroll
+    for (int q = 0; q < kL0Q; ++q) {
+        const int pq = min(pu * kL0Q + q, quads - 1);
+        *reinterpret_cast<uint4 *>(drow + pq * 16) = make_uint4(out[q][0], out[q][1], out[q][2], out[q][3]);
+    }
 }
 
 // Resize tables (host-built, OpenCV fixed-point): per destination column sx[x] and the
@@ -1356,7 +1366,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     if (prof) (void)hipEventRecord(ev[0], s);
     {
         const LevelGeom &L = G.lv[0];
-        int n = (L.pitch >> 4) * L.prows;
+        int n = (((L.pitch >> 4) + kL0Q - 1) / kL0Q) * L.prows;
         hipLaunchKernelGGL(k_pyr_level0, dim3((n + 255) / 256, batch), dim3(256), 0, s, d_images, stride,
                            frame_stride, e->d_pyr, G);
         for (int l = 1; l < G.nlevels; ++l) {
