@@ -991,35 +991,29 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
                               s[0][3] | (s[1][3] << 16));
     }
     __syncthreads();
-    // column pass: item = (output row, group); rows are permuted inside blocks of 8 so that the four
-    // rows of a wavefront share their parity (no divergence between the even/odd pairings)
+    // column pass: item = (output row pair, group).  Rows 2p and 2p+1 read the same four staged pair-rows: the even
+    // row pairs the taps (w0,w1)(w2,w3)(w4,w5)+w6 with them, the odd row w0+(w1,w2)(w3,w4)(w5,w6).
     const uint32_t w01 = (uint32_t)W.w[0] | ((uint32_t)W.w[1] << 16), w23 = (uint32_t)W.w[2] | ((uint32_t)W.w[3] << 16),
                    w45 = (uint32_t)W.w[4] | ((uint32_t)W.w[5] << 16), w12 = (uint32_t)W.w[1] | ((uint32_t)W.w[2] << 16),
                    w34 = (uint32_t)W.w[3] | ((uint32_t)W.w[4] << 16), w56 = (uint32_t)W.w[5] | ((uint32_t)W.w[6] << 16);
-    const int nrows8 = (rows + 7) & ~7;
-    for (int it = tid; it < nrows8 * 16; it += 256) {
-        const int q = it >> 4, g = it & 15;
-        const int y = (q & ~7) | ((q & 3) << 1) | ((q >> 2) & 1);
-        if (y >= rows || x0 + 4 * g >= L.w) continue;
-        const int p = y >> 1;
+    const int nprow = (rows + 1) >> 1;
+    for (int it = tid; it < nprow * 16; it += 256) {
+        const int p = it >> 4, g = it & 15;
+        if (x0 + 4 * g >= L.w) continue;
         const uint4 P0 = srow[p * 16 + g], P1 = srow[(p + 1) * 16 + g], P2 = srow[(p + 2) * 16 + g], P3 = srow[(p + 3) * 16 + g];
         const uint32_t a0[4] = {P0.x, P0.y, P0.z, P0.w}, a1[4] = {P1.x, P1.y, P1.z, P1.w},
                        a2[4] = {P2.x, P2.y, P2.z, P2.w}, a3[4] = {P3.x, P3.y, P3.z, P3.w};
-        uint32_t res = 0;
-        if ((y & 1) == 0) {
+        uint32_t rese = 0, reso = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t acc = udot2(a0[j], w01, udot2(a1[j], w23, udot2(a2[j], w45, __umul24(a3[j] & 0xffffu, (uint32_t)W.w[6]))));
-                res |= min((acc + 32768u) >> 16, 255u) << (8 * j);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t acc = udot2(a1[j], w12, udot2(a2[j], w34, udot2(a3[j], w56, __umul24(a0[j] >> 16, (uint32_t)W.w[0]))));
-                res |= min((acc + 32768u) >> 16, 255u) << (8 * j);
-            }
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t acce = udot2(a0[j], w01, udot2(a1[j], w23, udot2(a2[j], w45, __umul24(a3[j] & 0xffffu, (uint32_t)W.w[6]))));
+            const uint32_t acco = udot2(a1[j], w12, udot2(a2[j], w34, udot2(a3[j], w56, __umul24(a0[j] >> 16, (uint32_t)W.w[0]))));
+            rese |= min((acce + 32768u) >> 16, 255u) << (8 * j);
+            reso |= min((acco + 32768u) >> 16, 255u) << (8 * j);
         }
-        *reinterpret_cast<uint32_t *>(out + (uint32_t)(__mul24(y0 + y, L.pitch) + x0 + 4 * g)) = res;
+        uint8_t *o = out + (uint32_t)(__mul24(y0 + 2 * p, L.pitch) + x0 + 4 * g);
+        *reinterpret_cast<uint32_t *>(o) = rese;
+        if (2 * p + 1 < rows) *reinterpret_cast<uint32_t *>(o + L.pitch) = reso;
     }
 }
 
