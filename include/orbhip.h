@@ -25,6 +25,8 @@
  *                                     (src/ORBmatcher.cc:290-403, loop closing)
  *   orbhip_search_best_in_window      inner search of ORBmatcher::Fuse x2 (src/ORBmatcher.cc:825-1100) and of both
  *                                     directions of SearchBySim3 (:1102-1326)
+ *   orbhip_assign_features_to_grid    Frame::AssignFeaturesToGrid (src/Frame.cc:230-245)
+ *   orbhip_compute_stereo_from_rgbd   Frame::ComputeStereoFromRGBD (src/Frame.cc:643-664)
  *   orbhip_distinctive_descriptors    MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307), batched
  *   orbhip_vocabulary_*               ORBVocabulary (DBoW2::TemplatedVocabulary<FORB>) loadFromTextFile + transform,
  *                                     i.e. Frame::ComputeBoW (src/Frame.cc:395-402)
@@ -263,6 +265,30 @@ int orbhip_search_for_triangulation(orbhip_matcher *m, const orbhip_frame_view *
  * At most 2048 observations per map point (ORBHIP_E_CAPACITY otherwise). */
 int orbhip_distinctive_descriptors(orbhip_matcher *m, const uint8_t *desc, const int32_t *offsets, int npoints,
                                    int32_t *best_idx);
+
+/* ---- Frame constructor glue either side of the path (rectified / undistorted cameras) -------------------------
+ * Frame::AssignFeaturesToGrid (src/Frame.cc:230-245, PosInGrid :382-392): the 64 x 48 grid mGrid as CSR in the order
+ * GetFeaturesInArea walks it.  cell c = posX*48 + posY; cell_of[n] = c or -1 (PosInGrid rejects the keypoint);
+ * cell_start[64*48 + 1]; cell_items[n] (the first cell_start[3072] entries are used): keypoint indices of every cell
+ * in push_back (ascending) order.  f->keys are mvKeysUn.  n <= 4096. */
+int orbhip_assign_features_to_grid(orbhip_matcher *m, const orbhip_frame_view *f, int32_t *cell_of, int32_t *cell_start,
+                                   int32_t *cell_items);
+/* device-resident, batched: d_kps [frames][cap], d_n [frames]; outputs d_cell_of / d_cell_items [frames][cap] int32,
+ * d_cell_start [frames][3073] int32.  cap <= 4096.  Asynchronous on the matcher's stream. */
+int orbhip_assign_features_to_grid_device(orbhip_matcher *m, int frames, const void *d_kps, const void *d_n, int cap,
+                                          float min_x, float min_y, float grid_inv_w, float grid_inv_h, void *d_cell_of,
+                                          void *d_cell_start, void *d_cell_items);
+/* Frame::ComputeStereoFromRGBD (src/Frame.cc:643-664): depth = CV_32F image (rows x cols, stride in floats), sampled at
+ * the truncated coordinates of keys (mvKeys); u_right[i] = keys_un[i].x - mbf/d, depth_out[i] = d where d > 0, else
+ * -1 / -1.  keys_un null = keys.  A keypoint outside the image reads d = 0 (the reference would read out of bounds). */
+int orbhip_compute_stereo_from_rgbd(orbhip_matcher *m, const orbhip_keypoint *keys, const orbhip_keypoint *keys_un, int n,
+                                    const float *depth, int rows, int cols, int stride_floats, float mbf, float *u_right,
+                                    float *depth_out);
+/* device-resident, batched: frame f reads d_depth + f * frame_stride_floats; d_kps_un null = d_kps */
+int orbhip_compute_stereo_from_rgbd_device(orbhip_matcher *m, int frames, const void *d_kps, const void *d_kps_un,
+                                           const void *d_n, int cap, const void *d_depth, int rows, int cols,
+                                           int stride_floats, size_t frame_stride_floats, float mbf, void *d_u_right,
+                                           void *d_depth_out);
 
 /* ---- DBoW2 vocabulary: ORBVocabulary::loadFromTextFile + transform ---------------------------------------------
  * Replaces, for Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:395-402, src/KeyFrame.cc ComputeBoW), the

@@ -102,6 +102,9 @@ def lib():
         L.oracle_vocabulary_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_assign_features_to_grid.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_compute_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                                      C.c_void_p, C.c_void_p]
         L.oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                     C.c_void_p, C.c_int, C.POINTER(Pyramids),
                                                     C.c_int, C.c_float, C.c_float, C.c_void_p,
@@ -340,6 +343,26 @@ def distinctive_descriptor(desc):
     """MapPoint::ComputeDistinctiveDescriptors for one map point; index of the chosen observation or -1."""
     d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
     return lib().oracle_distinctive_descriptor(_p(d), len(d))
+
+
+def assign_features_to_grid(frame):
+    """Frame::AssignFeaturesToGrid; returns (cell_of[n], cell_start[3073], cell_items[m])."""
+    cell_of = np.zeros(max(frame.n, 1), np.int32)
+    start = np.zeros(64 * 48 + 1, np.int32)
+    items = np.zeros(max(frame.n, 1), np.int32)
+    lib().oracle_assign_features_to_grid(C.byref(frame), _p(cell_of), _p(start), _p(items))
+    return cell_of[:frame.n].copy(), start, items[:start[-1]].copy()
+
+
+def compute_stereo_from_rgbd(keys, keys_un, depth, mbf):
+    """Frame::ComputeStereoFromRGBD; depth: 2-D float32 image.  Returns (mvuRight, mvDepth)."""
+    k = np.ascontiguousarray(keys, KP_DTYPE)
+    ku = np.ascontiguousarray(keys_un, KP_DTYPE)
+    d = np.ascontiguousarray(depth, np.float32)
+    ur = np.zeros(max(len(k), 1), np.float32)
+    dp = np.zeros(max(len(k), 1), np.float32)
+    lib().oracle_compute_stereo_from_rgbd(_p(k), _p(ku), len(k), _p(d), d.shape[1], mbf, _p(ur), _p(dp))
+    return ur[:len(k)].copy(), dp[:len(k)].copy()
 
 
 def compute_stereo_matches(keys_l, desc_l, keys_r, desc_r, levels_l, levels_r, scale, inv_scale,

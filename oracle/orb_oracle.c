@@ -1356,6 +1356,45 @@ int oracle_distinctive_descriptor(const uint8_t *desc, int N)
     return BestIdx;
 }
 
+/* Frame::AssignFeaturesToGrid, Frame.cc:230-245 with PosInGrid :382-392.  mGrid[64][48] as CSR in the order
+ * GetFeaturesInArea walks it: cell c = posX*48 + posY, cell_start[c] .. cell_start[c+1] index cell_items, items in
+ * push_back (= ascending keypoint index) order; cell_of[i] = c or -1 when PosInGrid rejects the keypoint. */
+void oracle_assign_features_to_grid(const oracle_frame *f, int32_t *cell_of, int32_t *cell_start, int32_t *cell_items)
+{
+    const int ncell = FRAME_GRID_COLS * FRAME_GRID_ROWS;
+    int *cnt = (int *)calloc(ncell + 1, sizeof(int));
+    for (int i = 0; i < f->n; ++i) {
+        const oracle_kp *kp = &f->keys[i];
+        const int posX = (int)roundf((kp->x - f->min_x) * f->grid_inv_w);
+        const int posY = (int)roundf((kp->y - f->min_y) * f->grid_inv_h);
+        if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) { cell_of[i] = -1; continue; }
+        cell_of[i] = posX * FRAME_GRID_ROWS + posY;
+        cnt[cell_of[i]]++;
+    }
+    cell_start[0] = 0;
+    for (int c = 0; c < ncell; ++c) cell_start[c + 1] = cell_start[c] + cnt[c];
+    memset(cnt, 0, sizeof(int) * ncell);
+    for (int i = 0; i < f->n; ++i)
+        if (cell_of[i] >= 0) cell_items[cell_start[cell_of[i]] + cnt[cell_of[i]]++] = i;
+    free(cnt);
+}
+
+/* Frame::ComputeStereoFromRGBD, Frame.cc:643-664: depth image CV_32F sampled at the DISTORTED keypoint (float
+ * coordinates truncated by Mat::at<float>(int,int)); mvuRight from the undistorted x. */
+void oracle_compute_stereo_from_rgbd(const oracle_kp *keys, const oracle_kp *keys_un, int n, const float *depth,
+                                     int stride_floats, float mbf, float *u_right, float *depth_out)
+{
+    for (int i = 0; i < n; ++i) {
+        u_right[i] = -1.0f; depth_out[i] = -1.0f;
+        const float v = keys[i].y, u = keys[i].x;
+        const float d = depth[(size_t)(int)v * stride_floats + (int)u];
+        if (d > 0) {
+            depth_out[i] = d;
+            u_right[i] = keys_un[i].x - mbf / d;
+        }
+    }
+}
+
 /* ---- DBoW2 vocabulary: loadFromTextFile + transform --------------------------------------------------------
  * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424 (text format), :1127-1199 (transform of a feature set),
  * :1218-1262 (descent of one feature), BowVector.cpp:36-88 (addWeight / addIfNotExist / normalize),

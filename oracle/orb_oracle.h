@@ -167,6 +167,12 @@ int oracle_search_for_triangulation(const oracle_frame *f1, const uint32_t *node
 /* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:242-307) for one map point with N observed descriptors */
 int oracle_distinctive_descriptor(const uint8_t *desc, int N);
 
+/* Frame::AssignFeaturesToGrid (Frame.cc:230-245): cell_of[n], cell_start[64*48+1], cell_items[n] (CSR of mGrid) */
+void oracle_assign_features_to_grid(const oracle_frame *f, int32_t *cell_of, int32_t *cell_start, int32_t *cell_items);
+/* Frame::ComputeStereoFromRGBD (Frame.cc:643-664) */
+void oracle_compute_stereo_from_rgbd(const oracle_kp *keys, const oracle_kp *keys_un, int n, const float *depth,
+                                     int stride_floats, float mbf, float *u_right, float *depth_out);
+
 /* DBoW2 vocabulary (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h): loadFromTextFile :1338-1424 and
  * transform(features, BowVector, FeatureVector, levelsup) :1127-1199 as called by Frame::ComputeBoW (Frame.cc:395-402,
  * levelsup = 4).  Returns the BowVector size; per-feature word id / weight / FeatureVector node id, and the

@@ -997,6 +997,95 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__
     if (lane == 0) best[p] = bestIdx;
 }
 
+// ---- Frame constructor glue on the device ------------------------------------------------
+// Frame::AssignFeaturesToGrid (Frame.cc:230-245): mGrid[64][48] as CSR.  One workgroup per frame: keys
+// (cell << 12 | index) are bitonic-sorted in LDS, which is push_back order inside every cell; cell sizes come from LDS
+// atomics and an exclusive scan.
+constexpr int kGridMax = 4096, kGridCells = GRID_COLS * GRID_ROWS;
+__global__ __launch_bounds__(1024) void k_grid_csr(DevFrame F, Batch B, int *__restrict__ cell_of,
+                                                   int *__restrict__ cell_start, int *__restrict__ cell_items)
+{
+    __shared__ uint32_t key[kGridMax];
+    __shared__ int cnt[kGridCells + 1];
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, NT = 1024, frame = blockIdx.x;
+    batch_frame(F, B, frame);
+    cell_of += (size_t)frame * B.cap;
+    cell_items += (size_t)frame * B.cap;
+    cell_start += (size_t)frame * (kGridCells + 1);
+    const int n = min(F.n, kGridMax);
+    int P = 1024;
+    while (P < n) P <<= 1;
+    for (int c = tid; c <= kGridCells; c += NT) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < P; i += NT) {
+        uint32_t k = 0xffffffffu;
+        if (i < n) {
+            const orbhip_keypoint kp = F.keys[i];
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.min_x), F.inv_w));
+            const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, F.min_y), F.inv_h));
+            const bool in = !(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS);
+            const int c = px * GRID_ROWS + py;
+            cell_of[i] = in ? c : -1;
+            if (in) { k = ((uint32_t)c << 12) | (uint32_t)i; atomicAdd(&cnt[c], 1); }
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += NT) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = key[i], b = key[l];
+                    if ((a > b) == ((i & k) == 0)) { key[i] = b; key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < n; i += NT)
+        if (key[i] != 0xffffffffu) cell_items[i] = (int)(key[i] & 0xfffu);
+    // exclusive scan of the 3072 cell sizes: 3 per thread, wave scan, then the 16 wave totals
+    const int c0 = tid * 3;
+    const int v0 = cnt[c0], v1 = cnt[c0 + 1], v2 = cnt[c0 + 2];
+    int incl = v0 + v1 + v2;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    const int excl = base + incl - (v0 + v1 + v2);
+    cell_start[c0] = excl; cell_start[c0 + 1] = excl + v0; cell_start[c0 + 2] = excl + v0 + v1;
+    if (tid == NT - 1) cell_start[kGridCells] = excl + v0 + v1 + v2;
+}
+
+// Frame::ComputeStereoFromRGBD (Frame.cc:643-664)
+__global__ void k_stereo_from_rgbd(const orbhip_keypoint *__restrict__ keys, const orbhip_keypoint *__restrict__ keys_un,
+                                   const int *__restrict__ n_dev, int n, int cap, const float *__restrict__ depth, int rows,
+                                   int cols, int stride, size_t frame_stride, float mbf, float *__restrict__ u_right,
+                                   float *__restrict__ depth_out)
+{
+    const int frame = blockIdx.y;
+    keys += (size_t)frame * cap; keys_un += (size_t)frame * cap;
+    u_right += (size_t)frame * cap; depth_out += (size_t)frame * cap;
+    depth += (size_t)frame * frame_stride;
+    if (n_dev) n = min(n_dev[frame], cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v = (int)keys[i].y, u = (int)keys[i].x;      // Mat::at<float>(int,int) with float arguments: truncation
+    float d = 0.f;
+    if (v >= 0 && v < rows && u >= 0 && u < cols) d = depth[(size_t)v * stride + u];
+    float ur = -1.0f, dp = -1.0f;
+    if (d > 0) { dp = d; ur = __fsub_rn(keys_un[i].x, __fdiv_rn(mbf, d)); }
+    u_right[i] = ur;
+    depth_out[i] = dp;
+}
+
 // ---- Frame::ComputeStereoMatches (Frame.cc:466-640) -----------------------------------------
 struct StereoGeom {
     int nlevels, nrows;
@@ -1651,6 +1740,115 @@ int orbhip_search_by_projection_sim3(orbhip_matcher *m, const orbhip_frame_view 
 {
     if (!m || !kf || (nq > 0 && (!q || !qdesc)) || !assign || !nmatches || nq < 0) return ORBHIP_E_ARG;
     return run_search(m, 0, kf, q, qdesc, nullptr, nq, matched, 0.f, 0, assign, kf->n, nmatches, TH_LOW, 1, 0);
+}
+
+int orbhip_assign_features_to_grid_device(orbhip_matcher *m, int frames, const void *d_kps, const void *d_n, int cap,
+                                          float min_x, float min_y, float grid_inv_w, float grid_inv_h, void *d_cell_of,
+                                          void *d_cell_start, void *d_cell_items)
+{
+    if (!m || frames < 0 || cap < 1 || !d_kps || !d_n || !d_cell_of || !d_cell_start || !d_cell_items) return ORBHIP_E_ARG;
+    if (cap > kGridMax) { set_error("assign_features_to_grid: capacity %d exceeds %d", cap, kGridMax); return ORBHIP_E_CAPACITY; }
+    if (frames == 0) return ORBHIP_OK;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    DevFrame D;
+    D.n = 0; D.keys = (const orbhip_keypoint *)d_kps; D.desc = nullptr; D.u_right = nullptr;
+    D.min_x = min_x; D.min_y = min_y; D.inv_w = grid_inv_w; D.inv_h = grid_inv_h;
+    const Batch B = {(const int *)d_n, nullptr, cap, 0};
+    hipLaunchKernelGGL(k_grid_csr, dim3(frames), dim3(1024), 0, m->stream, D, B, (int *)d_cell_of, (int *)d_cell_start,
+                       (int *)d_cell_items);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_assign_features_to_grid(orbhip_matcher *m, const orbhip_frame_view *f, int32_t *cell_of, int32_t *cell_start,
+                                   int32_t *cell_items)
+{
+    if (!m || !f || f->n < 0 || !cell_start || (f->n > 0 && (!f->keys || !cell_of || !cell_items))) return ORBHIP_E_ARG;
+    const int n = f->n;
+    if (n > kGridMax) { set_error("assign_features_to_grid: %d keypoints exceed %d", n, kGridMax); return ORBHIP_E_CAPACITY; }
+    if (n == 0) { for (int c = 0; c <= kGridCells; ++c) cell_start[c] = 0; return ORBHIP_OK; }
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    Stage st;
+    int rc;
+    if ((rc = stage_begin(m, al256((size_t)n * sizeof(orbhip_keypoint)) + 256, &st))) return rc;
+    const void *d_keys = st.put(f->keys, (size_t)n * sizeof(orbhip_keypoint));
+    int *hn = reinterpret_cast<int *>(st.h + st.off);
+    *hn = n;
+    const void *d_n = st.put(nullptr, 0);
+    st.off += 256;
+    if ((rc = stage_commit(m, &st))) return rc;
+    const size_t ob = ((size_t)2 * n + kGridCells + 1) * sizeof(int);
+    void *p;
+    if ((rc = scratch(m, S_OUT, ob, &p))) return rc;
+    int *d_out = (int *)p;
+    uint8_t *h_out;
+    if ((rc = out_buffer(m, ob, &h_out))) return rc;
+    if ((rc = orbhip_assign_features_to_grid_device(m, 1, d_keys, d_n, n, f->min_x, f->min_y, f->grid_inv_w, f->grid_inv_h,
+                                                    d_out, d_out + 2 * n, d_out + n))) return rc;
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, ob, hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    const int *r = reinterpret_cast<const int *>(h_out);
+    memcpy(cell_of, r, (size_t)n * sizeof(int));
+    memcpy(cell_items, r + n, (size_t)n * sizeof(int));
+    memcpy(cell_start, r + 2 * n, (size_t)(kGridCells + 1) * sizeof(int));
+    return ORBHIP_OK;
+}
+
+int orbhip_compute_stereo_from_rgbd_device(orbhip_matcher *m, int frames, const void *d_kps, const void *d_kps_un,
+                                           const void *d_n, int cap, const void *d_depth, int rows, int cols,
+                                           int stride_floats, size_t frame_stride_floats, float mbf, void *d_u_right,
+                                           void *d_depth_out)
+{
+    if (!m || frames < 0 || cap < 1 || !d_kps || !d_n || !d_depth || rows < 1 || cols < 1 || stride_floats < cols ||
+        !d_u_right || !d_depth_out)
+        return ORBHIP_E_ARG;
+    if (frames == 0) return ORBHIP_OK;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    hipLaunchKernelGGL(k_stereo_from_rgbd, dim3((cap + 255) / 256, frames), dim3(256), 0, m->stream,
+                       (const orbhip_keypoint *)d_kps, (const orbhip_keypoint *)(d_kps_un ? d_kps_un : d_kps), (const int *)d_n,
+                       0, cap, (const float *)d_depth, rows, cols, stride_floats, frame_stride_floats, mbf, (float *)d_u_right,
+                       (float *)d_depth_out);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_compute_stereo_from_rgbd(orbhip_matcher *m, const orbhip_keypoint *keys, const orbhip_keypoint *keys_un, int n,
+                                    const float *depth, int rows, int cols, int stride_floats, float mbf, float *u_right,
+                                    float *depth_out)
+{
+    if (!m || n < 0 || (n > 0 && (!keys || !u_right || !depth_out)) || !depth || rows < 1 || cols < 1 || stride_floats < cols)
+        return ORBHIP_E_ARG;
+    if (n == 0) return ORBHIP_OK;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    if (!keys_un) keys_un = keys;
+    // the depth image travels like the grey image does for extraction: packed rows through the pinned staging buffer
+    Stage st;
+    int rc;
+    const size_t kb = al256((size_t)n * sizeof(orbhip_keypoint)), ib = al256((size_t)rows * cols * sizeof(float));
+    if ((rc = stage_begin(m, 2 * kb + ib + 256, &st))) return rc;
+    const void *d_keys = st.put(keys, (size_t)n * sizeof(orbhip_keypoint));
+    const void *d_un = st.put(keys_un, (size_t)n * sizeof(orbhip_keypoint));
+    float *hd = reinterpret_cast<float *>(st.h + st.off);
+    const void *d_depth = st.put(nullptr, 0);
+    for (int r = 0; r < rows; ++r) memcpy(hd + (size_t)r * cols, depth + (size_t)r * stride_floats, (size_t)cols * sizeof(float));
+    st.off += ib;
+    int *hn = reinterpret_cast<int *>(st.h + st.off);
+    *hn = n;
+    const void *d_n = st.put(nullptr, 0);
+    st.off += 256;
+    if ((rc = stage_commit(m, &st))) return rc;
+    void *p;
+    if ((rc = scratch(m, S_OUT, (size_t)2 * n * sizeof(float), &p))) return rc;
+    float *d_out = (float *)p;
+    uint8_t *h_out;
+    if ((rc = out_buffer(m, (size_t)2 * n * sizeof(float), &h_out))) return rc;
+    if ((rc = orbhip_compute_stereo_from_rgbd_device(m, 1, d_keys, d_un, d_n, n, d_depth, rows, cols, cols, 0, mbf, d_out,
+                                                     d_out + n))) return rc;
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)2 * n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    memcpy(u_right, h_out, (size_t)n * sizeof(float));
+    memcpy(depth_out, h_out + (size_t)n * sizeof(float), (size_t)n * sizeof(float));
+    return ORBHIP_OK;
 }
 
 int orbhip_distinctive_descriptors(orbhip_matcher *m, const uint8_t *desc, const int32_t *offsets, int npoints,

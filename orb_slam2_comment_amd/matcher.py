@@ -217,6 +217,30 @@ class ORBmatcher:
               "orbhip_distinctive_descriptors")
         return best[:len(lens)].copy()
 
+    # -- Frame constructor glue --------------------------------------------------
+    def AssignFeaturesToGrid(self, F):
+        """Frame::AssignFeaturesToGrid (src/Frame.cc:230-245).  Returns (cell_of[n], cell_start[3073], cell_items[m]):
+        mGrid[x][y] = cell_items[cell_start[x*48+y] : cell_start[x*48+y+1]]."""
+        v = F.c_view()
+        cell_of = np.full(max(F.N, 1), -1, np.int32)
+        start = np.zeros(FRAME_GRID_COLS * FRAME_GRID_ROWS + 1, np.int32)
+        items = np.zeros(max(F.N, 1), np.int32)
+        check(self._lib.orbhip_assign_features_to_grid(self._h, C.byref(v), ptr(cell_of), ptr(start), ptr(items)),
+              "orbhip_assign_features_to_grid")
+        return cell_of[:F.N].copy(), start, items[:start[-1]].copy()
+
+    def ComputeStereoFromRGBD(self, keys, keys_un, imDepth, mbf):
+        """Frame::ComputeStereoFromRGBD (src/Frame.cc:643-664); imDepth: 2-D float32.  Returns (mvuRight, mvDepth)."""
+        k = np.ascontiguousarray(keys, KP_DTYPE)
+        ku = k if keys_un is None else np.ascontiguousarray(keys_un, KP_DTYPE)
+        d = np.ascontiguousarray(imDepth, np.float32)
+        ur = np.full(max(len(k), 1), -1, np.float32)
+        dp = np.full(max(len(k), 1), -1, np.float32)
+        check(self._lib.orbhip_compute_stereo_from_rgbd(self._h, ptr(k), ptr(ku), len(k), ptr(d), d.shape[0], d.shape[1],
+                                                        d.shape[1], float(mbf), ptr(ur), ptr(dp)),
+              "orbhip_compute_stereo_from_rgbd")
+        return ur[:len(k)].copy(), dp[:len(k)].copy()
+
     # -- device-resident, batched SearchByProjection ---------------------------
     def set_stream(self, stream):
         check(self._lib.orbhip_matcher_set_stream(self._h, stream), "orbhip_matcher_set_stream")

@@ -640,3 +640,72 @@ def test_search_by_bow_device_matches_host_api(env):
         assert gn[0] > 50
     with pytest.raises(pkg.OrbHipError):
         m.SearchByBoWDevice(1, 4097, side, 0, 1, side, 1, 1, d_m12.data_ptr(), d_nm.data_ptr())
+
+
+def test_frame_glue_grid_and_rgbd(env):
+    """Frame::AssignFeaturesToGrid and Frame::ComputeStereoFromRGBD (host and device-resident forms) vs the oracle;
+    the CSR grid must also reproduce GetFeaturesInArea's visiting order when walked cell-major."""
+    import torch
+    pkg, M, O = env
+    rng = np.random.default_rng(3)
+    W, H = 1241, 376
+    img = synth_frame(6, W, H)
+    ext = pkg.ORBextractor(2000, 1.2, 8, 20, 7)
+    kps, desc = ext(img)
+    sf = ext.GetScaleFactors()
+    kun = kps.copy()
+    kun["x"] += rng.uniform(-30, 30, len(kps)).astype(np.float32)     # "undistorted" keys partly outside the bounds
+    kun["y"] += rng.uniform(-30, 30, len(kps)).astype(np.float32)
+    bounds = (-12.5, -7.25, W + 9.0, H + 3.5)                          # bounds of an undistorted image (Frame.cc:436-463)
+    keep = []
+    gv = pkg.FrameView(kun, desc, sf, bounds)
+    ov = O.make_frame(kun, desc, None, bounds, sf, keep)
+    m = pkg.ORBmatcher()
+    cell_of, start, items = m.AssignFeaturesToGrid(gv)
+    ocell, ostart, oitems = O.assign_features_to_grid(ov)
+    assert np.array_equal(cell_of, ocell) and np.array_equal(start, ostart) and np.array_equal(items, oitems)
+    assert (cell_of == -1).sum() > 0 and start[-1] == (cell_of >= 0).sum()
+    # walking the CSR cell-major over a window = Frame::GetFeaturesInArea without the distance test
+    whole = np.concatenate([items[start[c]:start[c + 1]] for c in range(64 * 48)])
+    area = O.features_in_area(ov, W / 2.0, H / 2.0, 1e6)
+    assert np.array_equal(whole, area)
+    # RGB-D: depth image with holes (0), negatives and NaN-free positives
+    depth = rng.uniform(0.3, 40.0, (H, W)).astype(np.float32)
+    depth[rng.random((H, W)) < 0.2] = 0.0
+    depth[rng.random((H, W)) < 0.05] = -1.0
+    ur, dp = m.ComputeStereoFromRGBD(kps, kun, depth, 386.1448)
+    our, odp = O.compute_stereo_from_rgbd(kps, kun, depth, np.float32(386.1448))
+    assert np.array_equal(ur, our) and np.array_equal(dp, odp)
+    assert (dp > 0).sum() > 0.5 * len(kps) and (dp == -1).sum() > 0.1 * len(kps)
+    # device-resident batch of 2 frames (second one empty)
+    dev = torch.device("cuda:0")
+    cap = len(kps) + 7
+    dk = torch.zeros((2, cap, 28), dtype=torch.uint8, device=dev)
+    dku = torch.zeros((2, cap, 28), dtype=torch.uint8, device=dev)
+    dk[0, :len(kps)] = torch.from_numpy(kps.view(np.uint8).reshape(-1, 28)).to(dev)
+    dku[0, :len(kps)] = torch.from_numpy(kun.view(np.uint8).reshape(-1, 28)).to(dev)
+    dn = torch.tensor([len(kps), 0], dtype=torch.int32, device=dev)
+    d_cell = torch.full((2, cap), -9, dtype=torch.int32, device=dev)
+    d_items = torch.full((2, cap), -9, dtype=torch.int32, device=dev)
+    d_start = torch.full((2, 64 * 48 + 1), -9, dtype=torch.int32, device=dev)
+    L = pkg.capi.lib()
+    b = [np.float32(v) for v in bounds]
+    pkg.capi.check(L.orbhip_assign_features_to_grid_device(m._h, 2, dku.data_ptr(), dn.data_ptr(), cap, b[0], b[1],
+                                                           np.float32(64) / (b[2] - b[0]), np.float32(48) / (b[3] - b[1]),
+                                                           d_cell.data_ptr(), d_start.data_ptr(), d_items.data_ptr()),
+                   "orbhip_assign_features_to_grid_device")
+    dd = torch.from_numpy(np.stack([depth, depth])).to(dev)
+    d_ur = torch.zeros((2, cap), dtype=torch.float32, device=dev)
+    d_dp = torch.zeros((2, cap), dtype=torch.float32, device=dev)
+    pkg.capi.check(L.orbhip_compute_stereo_from_rgbd_device(m._h, 2, dk.data_ptr(), dku.data_ptr(), dn.data_ptr(), cap,
+                                                            dd.data_ptr(), H, W, W, H * W, np.float32(386.1448),
+                                                            d_ur.data_ptr(), d_dp.data_ptr()),
+                   "orbhip_compute_stereo_from_rgbd_device")
+    m.sync()
+    assert np.array_equal(d_cell[0, :len(kps)].cpu().numpy(), ocell)
+    assert np.array_equal(d_start[0].cpu().numpy(), ostart) and np.array_equal(d_items[0, :ostart[-1]].cpu().numpy(), oitems)
+    assert (d_start[1].cpu().numpy() == 0).all()
+    assert np.array_equal(d_ur[0, :len(kps)].cpu().numpy(), our) and np.array_equal(d_dp[0, :len(kps)].cpu().numpy(), odp)
+    with pytest.raises(pkg.OrbHipError):
+        big = np.zeros(4097, pkg.KP_DTYPE)
+        m.AssignFeaturesToGrid(pkg.FrameView(big, np.zeros((4097, 32), np.uint8), sf, bounds))

@@ -461,3 +461,22 @@ def test_distinctive_descriptor_hand_worked(oracle):
     assert oracle.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == -1
     # N=2 -> index 0 -> every median is the self distance 0 -> first observation
     assert oracle.distinctive_descriptor(np.stack([c, z])) == 0
+
+
+def test_grid_and_rgbd_hand_worked(oracle):
+    """Frame.cc:230-245 / :382-392: cell = round((pt - min) * inv) (round, not floor), rejected outside 64 x 48;
+    Frame.cc:643-664: depth sampled at the truncated distorted coordinates, uRight from the undistorted x."""
+    # 640 x 480 bounds: inv = 0.1 in both directions -> cell (x/10 rounded, y/10 rounded)
+    f, keep = _mini_frame(oracle, [(4.9, 0.0), (5.1, 14.9), (5.0, 15.0), (634.9, 474.9), (635.1, 100.0), (12.0, 3.0)],
+                          np.zeros((6, 32), np.uint8))
+    cell_of, start, items = oracle.assign_features_to_grid(f)
+    # roundf: 0.49 -> 0, 0.51 -> 1, 0.5 -> 1 (half away from zero), 1.49 -> 1, 1.5 -> 2; 63.49 -> 63, 63.51 -> 64 (rejected)
+    assert cell_of.tolist() == [0 * 48 + 0, 1 * 48 + 1, 1 * 48 + 2, 63 * 48 + 47, -1, 1 * 48 + 0]
+    assert start[-1] == 5 and items.tolist() == [0, 5, 1, 2, 3]          # cell-major, push_back order inside a cell
+    assert start[48] == 1 and start[49] == 2 and start[50] == 3 and start[51] == 4
+    depth = np.zeros((480, 640), np.float32)
+    depth[14, 5] = 2.0; depth[15, 5] = -3.0; depth[0, 4] = 4.0
+    keys = np.zeros(3, oracle.KP_DTYPE); keys["x"] = [5.9, 5.0, 4.99]; keys["y"] = [14.9, 15.2, 0.5]
+    kun = keys.copy(); kun["x"] = [10.0, 20.0, 30.0]
+    ur, dp = oracle.compute_stereo_from_rgbd(keys, kun, depth, np.float32(8.0))
+    assert dp.tolist() == [2.0, -1.0, 4.0] and ur.tolist() == [6.0, -1.0, 28.0]
