@@ -1151,14 +1151,21 @@ using namespace orbhip;
 
 static int cv_round(double v) { return (int)lrint(v); }
 
+static void drop_graph(orbhip_extractor *e)
+{
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    e->graph_exec = nullptr; e->graph_batch = 0; e->graph_cap = 0;
+}
 static void free_geometry(orbhip_extractor *e)
 {
+    drop_graph(e);
     (void)hipFree(e->d_cells); (void)hipFree(e->d_tiles); (void)hipFree(e->d_tabs);
     e->d_cells = nullptr; e->d_tiles = nullptr; e->d_tabs = nullptr;
     e->bound = false;
 }
 static void free_batch(orbhip_extractor *e)
 {
+    drop_graph(e);
     (void)hipFree(e->d_pyr); (void)hipFree(e->d_blur); (void)hipFree(e->d_cell_cnt); (void)hipFree(e->d_cell_kp);
     (void)hipFree(e->d_keys); (void)hipFree(e->d_knode); (void)hipFree(e->d_sel); (void)hipFree(e->d_sel_cnt); (void)hipFree(e->d_status);
     e->d_pyr = e->d_blur = nullptr; e->d_cell_cnt = nullptr; e->d_cell_kp = nullptr; e->d_keys = nullptr;
@@ -1517,6 +1524,7 @@ int orbhip_extractor_set_blur_kernel(orbhip_extractor *e, const int32_t w[7])
     for (int i = 0; i < 7; ++i) { if (w[i] < 0 || w[i] > 255) return ORBHIP_E_ARG; s += w[i]; }
     if (s > 257) { set_error("blur weights sum %d > 257 overflows the uint16 row pass", s); return ORBHIP_E_ARG; }
     for (int i = 0; i < 7; ++i) e->blurw.w[i] = w[i];
+    drop_graph(e);   // the weights are a by-value kernel argument of the captured launches
     return ORBHIP_OK;
 }
 
@@ -1552,11 +1560,13 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
     // staging buffers
     const size_t img_bytes = (size_t)batch * rows * cols;
     if (img_bytes > e->d_img_bytes) {
+        drop_graph(e);
         (void)hipFree(e->d_img); e->d_img = nullptr; e->d_img_bytes = 0;
         ORBHIP_HIP_CHECK(hipMalloc(&e->d_img, img_bytes));
         e->d_img_bytes = img_bytes;
     }
     if ((size_t)cap * batch > e->out_slots || batch > e->out_batch) {
+        drop_graph(e);
         (void)hipFree(e->d_okp); (void)hipFree(e->d_odesc); (void)hipFree(e->d_on);
         e->d_okp = nullptr; e->d_odesc = nullptr; e->d_on = nullptr;
         e->out_slots = 0; e->out_batch = 0;
@@ -1569,6 +1579,7 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
     }
     // host -> pinned staging (row copies on the CPU) -> one DMA
     if (img_bytes > e->h_in_bytes) {
+        drop_graph(e);
         if (e->h_in) (void)hipHostFree(e->h_in);
         e->h_in = nullptr; e->h_in_bytes = 0;
         ORBHIP_HIP_CHECK(hipHostMalloc((void **)&e->h_in, img_bytes, hipHostMallocDefault));
@@ -1576,6 +1587,7 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
     }
     const size_t out_bytes = (size_t)batch * (2 * sizeof(int) + (size_t)cap * (sizeof(orbhip_keypoint) + 32));
     if (out_bytes > e->h_out_bytes) {
+        drop_graph(e);
         if (e->h_out) (void)hipHostFree(e->h_out);
         e->h_out = nullptr; e->h_out_bytes = 0;
         ORBHIP_HIP_CHECK(hipHostMalloc((void **)&e->h_out, out_bytes, hipHostMallocDefault));
@@ -1588,18 +1600,47 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
         if (stride == cols) memcpy(dst, src, (size_t)rows * cols);
         else for (int r = 0; r < rows; ++r) memcpy(dst + (size_t)r * cols, src + (size_t)r * stride, cols);
     }
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img, e->h_in, img_bytes, hipMemcpyHostToDevice, e->stream));
     rc = ensure_batch(e, batch);
-    if (rc) return rc;
-    rc = launch_pipeline(e, e->d_img, batch, cols, (size_t)rows * cols, e->d_okp, e->d_odesc, cap, e->d_on, nullptr);
     if (rc) return rc;
     int *h_n = reinterpret_cast<int *>(e->h_out), *h_st = h_n + batch;
     orbhip_keypoint *h_kp = reinterpret_cast<orbhip_keypoint *>(h_st + batch);
     uint8_t *h_desc = reinterpret_cast<uint8_t *>(h_kp + (size_t)batch * cap);
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_n, e->d_on, batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_st, e->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_kp, e->d_okp, (size_t)batch * cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, e->stream));
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_desc, e->d_odesc, (size_t)batch * cap * 32, hipMemcpyDeviceToHost, e->stream));
+    auto enqueue = [&]() -> int {
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img, e->h_in, img_bytes, hipMemcpyHostToDevice, e->stream));
+        int r = launch_pipeline(e, e->d_img, batch, cols, (size_t)rows * cols, e->d_okp, e->d_odesc, cap, e->d_on, nullptr);
+        if (r) return r;
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(h_n, e->d_on, batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(h_st, e->d_status, batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(h_kp, e->d_okp, (size_t)batch * cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, e->stream));
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(h_desc, e->d_odesc, (size_t)batch * cap * 32, hipMemcpyDeviceToHost, e->stream));
+        return ORBHIP_OK;
+    };
+    // Every pointer and by-value argument of the sequence is fixed for a (geometry, batch, cap, buffers) combination:
+    // capture it once, replay it with one launch.  Anything that would change an argument drops the graph.
+    static const bool no_graph = getenv("ORBHIP_NO_GRAPH") != nullptr;
+    if (!e->profiling && !no_graph) {
+        if (!e->graph_exec || e->graph_batch != batch || e->graph_cap != cap) {
+            drop_graph(e);
+            hipGraph_t graph = nullptr;
+            ORBHIP_HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue();
+            const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
+            if (rc || ce != hipSuccess || !graph) {
+                if (graph) (void)hipGraphDestroy(graph);
+                set_error("stream capture of the extraction sequence failed: %s", hipGetErrorString(ce));
+                return rc ? rc : ORBHIP_E_HIP;
+            }
+            const hipError_t ie = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) { e->graph_exec = nullptr; set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ie)); return ORBHIP_E_HIP; }
+            e->graph_batch = batch; e->graph_cap = cap;
+        }
+        ORBHIP_HIP_CHECK(hipGraphLaunch(e->graph_exec, e->stream));
+        e->last_batch = batch;   // launch_pipeline's bookkeeping (a replay does not run it)
+    } else {
+        rc = enqueue();
+        if (rc) return rc;
+    }
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
     for (int b = 0; b < batch; ++b) {
         n[b] = h_n[b];
@@ -1637,6 +1678,7 @@ int orbhip_extractor_set_stream(orbhip_extractor *e, void *stream)
     if (!e) return ORBHIP_E_ARG;
     ORBHIP_HIP_CHECK(hipSetDevice(e->device));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    drop_graph(e);
     e->stream = stream ? (hipStream_t)stream : e->own_stream;
     return ORBHIP_OK;
 }

@@ -65,6 +65,10 @@ struct orbhip_extractor {
     orbhip_keypoint *d_okp = nullptr; uint8_t *d_odesc = nullptr; int *d_on = nullptr;
     size_t out_slots = 0;   // keypoint slots allocated in d_okp / d_odesc
     int out_batch = 0;      // entries allocated in d_on
+    // host-pointer API: H2D copy + 13 launches + 4 D2H copies captured once per (batch, cap) and replayed with one
+    // hipGraphLaunch -- a single frame is launch-bound, not GPU-bound
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_batch = 0, graph_cap = 0;
     // pinned host staging (pageable 2-D copies are an order of magnitude slower than one pinned DMA)
     uint8_t *h_in = nullptr; size_t h_in_bytes = 0;
     uint8_t *h_out = nullptr; size_t h_out_bytes = 0;
