@@ -291,3 +291,43 @@ def test_batch_with_frame_and_row_strides(mods):
         ok, od = ora.extract(np.ascontiguousarray(big[b, 10:10 + H, 16:16 + W]))
         assert_kps_equal(kps[b, :n[b]], ok, "frame %d" % b)
         assert np.array_equal(desc[b, :n[b]], od)
+
+
+def test_host_api_graph_replay_is_invalidated_correctly(mods):
+    """The host-pointer entry replays a captured hipGraph; every event that changes a captured argument must drop it:
+    batch size, capacity (new geometry), image size, blur weights, stream.  Results must not depend on the history."""
+    pkg, O = mods
+    ext = pkg.ORBextractor(500, 1.2, 8, 20, 7)
+    a, b = synth_frame(11, 640, 360), synth_frame(12, 640, 360)
+    big = synth_frame(13, 752, 480)
+    ref = {}
+    for name, img in (("a", a), ("b", b), ("big", big)):
+        ref[name] = O.OracleExtractor(500, 1.2, 8, 20, 7).extract(img)
+
+    def same(got, want):
+        assert_kps_equal(got[0], want[0])
+        assert np.array_equal(got[1], want[1])
+
+    same(ext(a), ref["a"])                      # capture (batch 1)
+    same(ext(b), ref["b"])                      # replay with new pixels
+    res = ext.extract_batch(np.stack([a, b, a]))            # batch 3: new graph
+    same(res[0], ref["a"]); same(res[1], ref["b"]); same(res[2], ref["a"])
+    same(ext(b), ref["b"])                      # back to batch 1
+    same(ext(big), ref["big"])                  # other image size: geometry rebinding
+    same(ext(a), ref["a"])
+    ext.set_blur_kernel([0, 0, 0, 255, 0, 0, 0])           # identity-like blur: descriptors change ...
+    k2, d2 = ext(a)
+    assert_kps_equal(k2, ref["a"][0])
+    assert not np.array_equal(d2, ref["a"][1])
+    ext.set_blur_kernel([18, 34, 49, 55, 49, 34, 18])      # ... and come back with the default weights
+    same(ext(a), ref["a"])
+    ext.set_profiling(True)                     # profiling path = plain launches
+    same(ext(b), ref["b"])
+    ext.set_profiling(False)
+    same(ext(b), ref["b"])
+    import torch
+    st = torch.cuda.Stream()
+    ext.set_stream(st.cuda_stream)
+    same(ext(a), ref["a"])                      # capture on the caller's stream
+    ext.set_stream(0)
+    same(ext(b), ref["b"])
