@@ -363,6 +363,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     const int lane = threadIdx.x;
     const size_t out_cell = (size_t)fr * G.ncells_total + cell;
     const int SW = F.strideW, SB = F.strideW * 4;
+    const int SS = F.scoreW * 4;                        // bytes per score-map row: detection width + 1-px zero halo, dword rounded
 
     if (dw <= 0 || dh <= 0) {  // cv::FAST on an image narrower than 7 px finds nothing
         if (lane == 0) cell_cnt[out_cell] = 0;
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             for (int u = 0; u < U; ++u) simg[min(i0 + u * 64 + lane, total - 1)] = v[u];
         }
     }
-    for (int i = lane; i < (dh + 2) * SW; i += 64) sscore[i] = 0;
+    for (int i = lane; i < (dh + 2) * F.scoreW; i += 64) sscore[i] = 0;
     __syncthreads();
 
     // column groups: group g covers LDS cols 4g..4g+3; valid centre cols [c_lo, c_hi)
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             brn = min3i(brn, min3i(mx9[9], mx9[10], mx9[11]), min3i(mx9[12], mx9[13], min(mx9[14], mx9[15])));
             const int sc = max(dark, -brn) - 1;       // cornerScore; corner at minTh <=> S >= minTh
             isc = sc >= tmin;
-            if (isc) score8[__mul24(y + 1, SB) + col] = (uint8_t)min(sc, 255);
+            if (isc) score8[__mul24(y + 1, SS) + (col - c_lo + 1)] = (uint8_t)min(sc, 255);   // score column = detection x + 1
         }
         const unsigned long long m = __ballot(isc);
         if (isc) slist[ncorn + lane_prefix(m)] = e;     // write index <= read index: in place is safe
@@ -510,10 +511,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         if (i < ncorn) {
             const unsigned short e = slist[i];
             const int y = e >> 7, col = e & 127;
-            const uint8_t *s = score8 + __mul24(y + 1, SB) + col;
+            const uint8_t *s = score8 + __mul24(y + 1, SS) + (col - c_lo + 1);
             const int v = s[0];
-            keep = v > s[-1] && v > s[1] && v > s[-SB - 1] && v > s[-SB] && v > s[-SB + 1] &&
-                   v > s[SB - 1] && v > s[SB] && v > s[SB + 1];
+            keep = v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] &&
+                   v > s[SS - 1] && v > s[SS] && v > s[SS + 1];
             key = ((uint32_t)e << 8) | (uint32_t)v;
         }
         const unsigned long long m = __ballot(keep);
@@ -1298,7 +1299,8 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         F.strideW = (mndw + 2) | 1;                       // margin + spare, odd: rows rotate over the LDS banks
         F.div_magic = ((1 << 20) + F.strideW - 1) / F.strideW;
         F.img_words = msh * F.strideW;
-        F.score_words = (mdh + 2) * F.strideW;
+        F.scoreW = (mdw + 2 + 3) >> 2;                     // the score map has its own, tighter row stride (LDS bytes decide
+        F.score_words = (mdh + 2) * F.scoreW;              // how many cells a CU holds: 5,340 B -> 4,7xx B = 29 -> 32 per CU)
         F.list_words = (mdw * mdh + 1) / 2 + 1;           // uint16 list: every pixel may pass the pre-test
         F.final_in_img = (slot_cap + 64 <= F.img_words) ? 1 : 0;
         e->fast_lds_bytes = (F.img_words + F.score_words + F.list_words + (F.final_in_img ? 0 : slot_cap + 64)) * 4;

@@ -12,6 +12,7 @@ constexpr int kBlurTW = 64, kBlurTH = 58;
 struct FastLds {
     int strideW;      // row stride in dwords (odd): 1 margin dword + staged dwords + 1 spare
     int div_magic;    // (i * div_magic) >> 20 == i / strideW for i < 8192
+    int scoreW;       // score-map row stride in dwords: (max detection width + 2 halo bytes) rounded up
     int img_words, score_words, list_words;
     int final_in_img; // NMS survivors alias the staged image (dead by then) when slot_cap + 64 <= img_words
 };
