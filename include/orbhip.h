@@ -25,6 +25,7 @@
  *                                     (src/ORBmatcher.cc:290-403, loop closing)
  *   orbhip_search_best_in_window      inner search of ORBmatcher::Fuse x2 (src/ORBmatcher.cc:825-1100) and of both
  *                                     directions of SearchBySim3 (:1102-1326)
+ *   orbhip_undistort_keypoints        Frame::UndistortKeyPoints (src/Frame.cc:404-434)
  *   orbhip_assign_features_to_grid    Frame::AssignFeaturesToGrid (src/Frame.cc:230-245)
  *   orbhip_compute_stereo_from_rgbd   Frame::ComputeStereoFromRGBD (src/Frame.cc:643-664)
  *   orbhip_distinctive_descriptors    MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:242-307), batched
@@ -278,6 +279,16 @@ int orbhip_assign_features_to_grid(orbhip_matcher *m, const orbhip_frame_view *f
 int orbhip_assign_features_to_grid_device(orbhip_matcher *m, int frames, const void *d_kps, const void *d_n, int cap,
                                           float min_x, float min_y, float grid_inv_w, float grid_inv_h, void *d_cell_of,
                                           void *d_cell_start, void *d_cell_items);
+/* Frame::UndistortKeyPoints (src/Frame.cc:404-434): keys_un = keys with pt replaced by
+ * cv::undistortPoints(pt, mK, mDistCoef, R = I, P = mK); dist5 = {k1, k2, p1, p2, k3} (mDistCoef, src/Tracking.cc:66-81,
+ * k3 = 0 when absent); dist5[0] == 0 copies the input (:406-410).  cv::undistortPoints is restated from the published
+ * algorithm of OpenCV 2.4 - 3.3 (double arithmetic, 5 fixed-point iterations): parity with a given OpenCV build is
+ * unpinned.  The four image corners of Frame::ComputeImageBounds (:436-463) go through the same call. */
+int orbhip_undistort_keypoints(orbhip_matcher *m, const orbhip_keypoint *keys, int n, float fx, float fy, float cx, float cy,
+                               const float *dist5, orbhip_keypoint *keys_un);
+/* device-resident, batched: d_kps / d_kps_un [frames][cap] (may be the same array), d_n [frames] */
+int orbhip_undistort_keypoints_device(orbhip_matcher *m, int frames, const void *d_kps, const void *d_n, int cap, float fx,
+                                      float fy, float cx, float cy, const float *dist5, void *d_kps_un);
 /* Frame::ComputeStereoFromRGBD (src/Frame.cc:643-664): depth = CV_32F image (rows x cols, stride in floats), sampled at
  * the truncated coordinates of keys (mvKeys); u_right[i] = keys_un[i].x - mbf/d, depth_out[i] = d where d > 0, else
  * -1 / -1.  keys_un null = keys.  A keypoint outside the image reads d = 0 (the reference would read out of bounds). */

@@ -105,6 +105,8 @@ def lib():
         L.oracle_assign_features_to_grid.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_compute_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float,
                                                       C.c_void_p, C.c_void_p]
+        L.oracle_undistort_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                 C.c_void_p, C.c_void_p]
         L.oracle_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                     C.c_void_p, C.c_int, C.POINTER(Pyramids),
                                                     C.c_int, C.c_float, C.c_float, C.c_void_p,
@@ -363,6 +365,16 @@ def compute_stereo_from_rgbd(keys, keys_un, depth, mbf):
     dp = np.zeros(max(len(k), 1), np.float32)
     lib().oracle_compute_stereo_from_rgbd(_p(k), _p(ku), len(k), _p(d), d.shape[1], mbf, _p(ur), _p(dp))
     return ur[:len(k)].copy(), dp[:len(k)].copy()
+
+
+def undistort_keypoints(keys, fx, fy, cx, cy, dist):
+    """Frame::UndistortKeyPoints; dist = (k1, k2, p1, p2, k3).  Returns mvKeysUn."""
+    k = np.ascontiguousarray(keys, KP_DTYPE)
+    d = np.zeros(5, np.float32)
+    d[:len(dist)] = dist
+    out = np.zeros(max(len(k), 1), KP_DTYPE)
+    lib().oracle_undistort_keypoints(_p(k), len(k), fx, fy, cx, cy, _p(d), _p(out))
+    return out[:len(k)].copy()
 
 
 def compute_stereo_matches(keys_l, desc_l, keys_r, desc_r, levels_l, levels_r, scale, inv_scale,

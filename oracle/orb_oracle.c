@@ -1395,6 +1395,41 @@ void oracle_compute_stereo_from_rgbd(const oracle_kp *keys, const oracle_kp *key
     }
 }
 
+/* Frame::UndistortKeyPoints, Frame.cc:404-434: cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK) on the keypoint
+ * coordinates; everything else of the KeyPoint is copied.  cv::undistortPoints is restated from OpenCV's published
+ * algorithm (cvUndistortPoints of OpenCV 2.4 - 3.3, imgproc/undistort.cpp; OpenCV is not on disk): float in, double
+ * arithmetic, normalise with the camera matrix, 5 fixed-point iterations of the inverse Brown model, re-project with
+ * P = mK, float out.  dist = {k1, k2, p1, p2, k3} (mDistCoef, Tracking.cc:66-81); dist[0] == 0 copies the input
+ * (:406-410).  Parity unpinned like every other OpenCV restatement. */
+void oracle_undistort_keypoints(const oracle_kp *keys, int n, float fxf, float fyf, float cxf, float cyf,
+                                const float *dist, oracle_kp *keys_un)
+{
+    for (int i = 0; i < n; ++i) keys_un[i] = keys[i];
+    if (dist[0] == 0.0f) return;
+    const double fx = fxf, fy = fyf, cx = cxf, cy = cyf, ifx = 1. / fx, ify = 1. / fy;
+    const double k0 = dist[0], k1 = dist[1], k2 = dist[2], k3 = dist[3], k4 = dist[4];
+    const double k5 = 0, k6 = 0, k7 = 0;   /* rational terms: absent from mDistCoef */
+    for (int i = 0; i < n; ++i) {
+        double x = keys[i].x, y = keys[i].y;
+        const double x0 = x = (x - cx) * ifx;
+        const double y0 = y = (y - cy) * ify;
+        for (int j = 0; j < 5; ++j) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k7 * r2 + k6) * r2 + k5) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+            const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x);
+            const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        /* RR = P * I with P = mK = [fx 0 cx; 0 fy cy; 0 0 1] */
+        const double xx = fx * x + 0.0 * y + cx;
+        const double yy = 0.0 * x + fy * y + cy;
+        const double ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+        keys_un[i].x = (float)(xx * ww);
+        keys_un[i].y = (float)(yy * ww);
+    }
+}
+
 /* ---- DBoW2 vocabulary: loadFromTextFile + transform --------------------------------------------------------
  * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1424 (text format), :1127-1199 (transform of a feature set),
  * :1218-1262 (descent of one feature), BowVector.cpp:36-88 (addWeight / addIfNotExist / normalize),

@@ -173,6 +173,10 @@ void oracle_assign_features_to_grid(const oracle_frame *f, int32_t *cell_of, int
 void oracle_compute_stereo_from_rgbd(const oracle_kp *keys, const oracle_kp *keys_un, int n, const float *depth,
                                      int stride_floats, float mbf, float *u_right, float *depth_out);
 
+/* Frame::UndistortKeyPoints (Frame.cc:404-434); dist = {k1, k2, p1, p2, k3} */
+void oracle_undistort_keypoints(const oracle_kp *keys, int n, float fx, float fy, float cx, float cy,
+                                const float *dist, oracle_kp *keys_un);
+
 /* DBoW2 vocabulary (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h): loadFromTextFile :1338-1424 and
  * transform(features, BowVector, FeatureVector, levelsup) :1127-1199 as called by Frame::ComputeBoW (Frame.cc:395-402,
  * levelsup = 4).  Returns the BowVector size; per-feature word id / weight / FeatureVector node id, and the

@@ -73,6 +73,8 @@ SYMBOLS = [
                                          _f, _i, _vp, _vp]),
     ("orbhip_search_for_triangulation", _i, [_vp, C.POINTER(FrameView), _vp, _vp, C.POINTER(FrameView), _vp, _vp, _vp, _f,
                                              _f, _vp, _i, _i, _vp, _pi]),
+    ("orbhip_undistort_keypoints", _i, [_vp, _vp, _i, _f, _f, _f, _f, _vp, _vp]),
+    ("orbhip_undistort_keypoints_device", _i, [_vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp]),
     ("orbhip_assign_features_to_grid", _i, [_vp, C.POINTER(FrameView), _vp, _vp, _vp]),
     ("orbhip_assign_features_to_grid_device", _i, [_vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp]),
     ("orbhip_compute_stereo_from_rgbd", _i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp]),

@@ -1064,6 +1064,42 @@ __global__ __launch_bounds__(1024) void k_grid_csr(DevFrame F, Batch B, int *__r
     if (tid == NT - 1) cell_start[kGridCells] = excl + v0 + v1 + v2;
 }
 
+// Frame::UndistortKeyPoints (Frame.cc:404-434) = cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK): OpenCV 2.4 - 3.3
+// cvUndistortPoints restated from its published algorithm (double arithmetic, 5 fixed-point iterations of the inverse
+// Brown model, re-projection with P = mK).  The translation unit is built with -ffp-contract=off, so every product
+// and sum below rounds exactly like the C oracle's.
+struct UndistortParams { double fx, fy, cx, cy, k[5]; };
+__global__ void k_undistort(const orbhip_keypoint *__restrict__ keys, const int *__restrict__ n_dev, int n, int cap,
+                            UndistortParams P, orbhip_keypoint *__restrict__ keys_un)
+{
+    const int frame = blockIdx.y;
+    keys += (size_t)frame * cap; keys_un += (size_t)frame * cap;
+    if (n_dev) n = min(n_dev[frame], cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    orbhip_keypoint kp = keys[i];
+    const double ifx = 1. / P.fx, ify = 1. / P.fy;
+    double x = kp.x, y = kp.y;
+    const double x0 = x = (x - P.cx) * ifx;
+    const double y0 = y = (y - P.cy) * ify;
+    const double k0 = P.k[0], k1 = P.k[1], k2 = P.k[2], k3 = P.k[3], k4 = P.k[4];
+#pragma unroll 1
+    for (int j = 0; j < 5; ++j) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+        const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x);
+        const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = P.fx * x + 0.0 * y + P.cx;
+    const double yy = 0.0 * x + P.fy * y + P.cy;
+    const double ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    kp.x = (float)(xx * ww);
+    kp.y = (float)(yy * ww);
+    keys_un[i] = kp;
+}
+
 // Frame::ComputeStereoFromRGBD (Frame.cc:643-664)
 __global__ void k_stereo_from_rgbd(const orbhip_keypoint *__restrict__ keys, const orbhip_keypoint *__restrict__ keys_un,
                                    const int *__restrict__ n_dev, int n, int cap, const float *__restrict__ depth, int rows,
@@ -1791,6 +1827,52 @@ int orbhip_assign_features_to_grid(orbhip_matcher *m, const orbhip_frame_view *f
     memcpy(cell_of, r, (size_t)n * sizeof(int));
     memcpy(cell_items, r + n, (size_t)n * sizeof(int));
     memcpy(cell_start, r + 2 * n, (size_t)(kGridCells + 1) * sizeof(int));
+    return ORBHIP_OK;
+}
+
+int orbhip_undistort_keypoints_device(orbhip_matcher *m, int frames, const void *d_kps, const void *d_n, int cap, float fx,
+                                      float fy, float cx, float cy, const float *dist5, void *d_kps_un)
+{
+    if (!m || frames < 0 || cap < 1 || !d_kps || !d_n || !dist5 || !d_kps_un || fx == 0.f || fy == 0.f) return ORBHIP_E_ARG;
+    if (frames == 0) return ORBHIP_OK;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    if (dist5[0] == 0.0f) {   // mvKeysUn = mvKeys (:406-410)
+        if (d_kps_un != d_kps)
+            ORBHIP_HIP_CHECK(hipMemcpyAsync(d_kps_un, d_kps, (size_t)frames * cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToDevice, m->stream));
+        return ORBHIP_OK;
+    }
+    UndistortParams P;
+    P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy;
+    for (int i = 0; i < 5; ++i) P.k[i] = dist5[i];
+    hipLaunchKernelGGL(k_undistort, dim3((cap + 255) / 256, frames), dim3(256), 0, m->stream, (const orbhip_keypoint *)d_kps,
+                       (const int *)d_n, 0, cap, P, (orbhip_keypoint *)d_kps_un);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_undistort_keypoints(orbhip_matcher *m, const orbhip_keypoint *keys, int n, float fx, float fy, float cx, float cy,
+                               const float *dist5, orbhip_keypoint *keys_un)
+{
+    if (!m || n < 0 || (n > 0 && (!keys || !keys_un)) || !dist5 || fx == 0.f || fy == 0.f) return ORBHIP_E_ARG;
+    if (n == 0) return ORBHIP_OK;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    Stage st;
+    int rc;
+    if ((rc = stage_begin(m, al256((size_t)n * sizeof(orbhip_keypoint)) + 256, &st))) return rc;
+    const void *d_keys = st.put(keys, (size_t)n * sizeof(orbhip_keypoint));
+    int *hn = reinterpret_cast<int *>(st.h + st.off);
+    *hn = n;
+    const void *d_n = st.put(nullptr, 0);
+    st.off += 256;
+    if ((rc = stage_commit(m, &st))) return rc;
+    void *p;
+    if ((rc = scratch(m, S_OUT, (size_t)n * sizeof(orbhip_keypoint), &p))) return rc;
+    uint8_t *h_out;
+    if ((rc = out_buffer(m, (size_t)n * sizeof(orbhip_keypoint), &h_out))) return rc;
+    if ((rc = orbhip_undistort_keypoints_device(m, 1, d_keys, d_n, n, fx, fy, cx, cy, dist5, p))) return rc;
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, p, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    memcpy(keys_un, h_out, (size_t)n * sizeof(orbhip_keypoint));
     return ORBHIP_OK;
 }
 

@@ -218,6 +218,16 @@ class ORBmatcher:
         return best[:len(lens)].copy()
 
     # -- Frame constructor glue --------------------------------------------------
+    def UndistortKeyPoints(self, keys, fx, fy, cx, cy, dist):
+        """Frame::UndistortKeyPoints (src/Frame.cc:404-434); dist = (k1, k2, p1, p2[, k3]).  Returns mvKeysUn."""
+        k = np.ascontiguousarray(keys, KP_DTYPE)
+        d = np.zeros(5, np.float32)
+        d[:len(dist)] = dist
+        out = np.zeros(max(len(k), 1), KP_DTYPE)
+        check(self._lib.orbhip_undistort_keypoints(self._h, ptr(k), len(k), fx, fy, cx, cy, ptr(d), ptr(out)),
+              "orbhip_undistort_keypoints")
+        return out[:len(k)].copy()
+
     def AssignFeaturesToGrid(self, F):
         """Frame::AssignFeaturesToGrid (src/Frame.cc:230-245).  Returns (cell_of[n], cell_start[3073], cell_items[m]):
         mGrid[x][y] = cell_items[cell_start[x*48+y] : cell_start[x*48+y+1]]."""

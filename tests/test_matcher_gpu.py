@@ -709,3 +709,38 @@ def test_frame_glue_grid_and_rgbd(env):
     with pytest.raises(pkg.OrbHipError):
         big = np.zeros(4097, pkg.KP_DTYPE)
         m.AssignFeaturesToGrid(pkg.FrameView(big, np.zeros((4097, 32), np.uint8), sf, bounds))
+
+
+def test_undistort_keypoints(env):
+    """Frame::UndistortKeyPoints: host and device-resident forms bit-identical to the oracle (fp64, no contraction)."""
+    import torch
+    pkg, M, O = env
+    rng = np.random.default_rng(2)
+    n = 3000
+    k = np.zeros(n, pkg.KP_DTYPE)
+    k["x"] = rng.uniform(-5, 760, n).astype(np.float32); k["y"] = rng.uniform(-5, 490, n).astype(np.float32)
+    k["angle"] = rng.uniform(0, 360, n).astype(np.float32); k["octave"] = rng.integers(0, 8, n); k["class_id"] = -1
+    m = pkg.ORBmatcher()
+    cases = ((458.654, 457.296, 367.215, 248.375, (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)),     # EuRoC.yaml
+             (517.306408, 516.469215, 318.643040, 255.313989, (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)),  # TUM1.yaml
+             (718.856, 718.856, 607.1928, 185.2157, (0.0, 0.0, 0.0, 0.0)))                                    # KITTI: copy
+    for fx, fy, cx, cy, dist in cases:
+        got = m.UndistortKeyPoints(k, fx, fy, cx, cy, dist)
+        want = O.undistort_keypoints(k, fx, fy, cx, cy, dist)
+        assert all(np.array_equal(got[f], want[f]) for f in k.dtype.names), dist
+    dev = torch.device("cuda:0")
+    cap = n + 5
+    dk = torch.zeros((2, cap, 28), dtype=torch.uint8, device=dev)
+    dk[0, :n] = torch.from_numpy(k.view(np.uint8).reshape(-1, 28)).to(dev)
+    dk[1, :100] = dk[0, 50:150]
+    dn = torch.tensor([n, 100], dtype=torch.int32, device=dev)
+    fx, fy, cx, cy, dist = cases[1]
+    d5 = np.array(dist, np.float32)
+    pkg.capi.check(pkg.capi.lib().orbhip_undistort_keypoints_device(m._h, 2, dk.data_ptr(), dn.data_ptr(), cap, fx, fy, cx, cy,
+                                                                    pkg.capi.ptr(d5), dk.data_ptr()), "undistort_device")   # in place
+    m.sync()
+    want = O.undistort_keypoints(k, fx, fy, cx, cy, dist)
+    got0 = dk[0, :n].cpu().numpy().view(pkg.KP_DTYPE).reshape(-1)
+    got1 = dk[1, :100].cpu().numpy().view(pkg.KP_DTYPE).reshape(-1)
+    assert all(np.array_equal(got0[f], want[f]) for f in k.dtype.names)
+    assert all(np.array_equal(got1[f], want[50:150][f]) for f in k.dtype.names)
