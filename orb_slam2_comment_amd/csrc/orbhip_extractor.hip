@@ -350,8 +350,6 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     uint32_t *simg = lds;                                   // staged sub-image
     uint32_t *sscore = lds + F.img_words;                   // score map, 1-px zero halo rows
     unsigned short *slist = reinterpret_cast<unsigned short *>(sscore + F.score_words);  // (y<<7)|col
-    // NMS survivors: the staged image is dead once the scores exist, so the finals reuse its LDS when they fit
-    uint32_t *sfinal = F.final_in_img ? simg : sscore + F.score_words + F.list_words;
 
     int cell, fr;
     xcd_remap(cell, fr);
@@ -400,12 +398,19 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     const int ngrp = g_hi - g_lo + 1;                   // <= 17
     const int nwork = ngrp * dh;                        // (row, group) work items, row-major
     const int magic = ((1 << 20) + ngrp - 1) / ngrp;    // exact floor(i/ngrp) for i < 4096
-    const int tmin = G.min_th;
-    const i16x2_t T2 = {(short)tmin, (short)tmin};
     const int list_dummy = F.list_words * 2 - 1;        // last uint16 of the list region: never a real entry
     const uint32_t vm_first = (0xfu << (c_lo & 3)) & 0xfu;       // valid centres of the first group of a row
     const uint32_t vm_last = 0xfu >> (3 - ((c_hi - 1) & 3));     // ... and of the last one
 
+    // Two passes instead of one at minThFAST: the reference calls FAST(iniThFAST) first and only cells that keep nothing go
+    // on to FAST(minThFAST) (:809-816).  A keypoint of the first call has S >= iniTh and beats its 8 neighbours' scores;
+    // neighbours that are not corners at iniTh have S < iniTh and cannot suppress it, so the first call needs the scores
+    // of the iniTh corners only -- a fraction of the minTh corners -- and textured cells never look at the rest.
+  uint32_t *out = cell_kp + out_cell * G.slot_cap;
+  int total = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int tmin = pass ? G.min_th : G.ini_th;
+    const i16x2_t T2 = {(short)tmin, (short)tmin};
     // ---- 2. dense pre-test (packed int16, two pixels per operation), survivors -> slist ----
     int nsurv = 0;
     for (int it0 = 0; it0 < nwork; it0 += 64) {
@@ -502,46 +507,43 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     }
     __syncthreads();
 
-    // ---- 4. NMS over the corner list ----
-    int nfin = 0, nini = 0;
+    // ---- 4. NMS over the corner list; the survivors stay in the list (in place: write index <= read index) ----
+    int nfin = 0;
     for (int i0 = 0; i0 < ncorn; i0 += 64) {
         const int i = i0 + lane;
         bool keep = false;
-        uint32_t key = 0;
+        unsigned short e = 0;
         if (i < ncorn) {
-            const unsigned short e = slist[i];
+            e = slist[i];
             const int y = e >> 7, col = e & 127;
             const uint8_t *s = score8 + __mul24(y + 1, SS) + (col - c_lo + 1);
             const int v = s[0];
             keep = v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] &&
                    v > s[SS - 1] && v > s[SS] && v > s[SS + 1];
-            key = ((uint32_t)e << 8) | (uint32_t)v;
         }
         const unsigned long long m = __ballot(keep);
-        if (keep) sfinal[nfin + lane_prefix(m)] = key;
+        if (keep) slist[nfin + lane_prefix(m)] = e;
         nfin += __popcll(m);
-        nini += __popcll(__ballot(keep && (int)(key & 0xff) >= G.ini_th));
     }
     __syncthreads();
+    if (nfin == 0 && pass == 0) continue;       // vKeysCell.empty() -> FAST(minThFAST); the score map keeps valid entries
 
-    // ---- 5. threshold fallback; the list is already row-major, so the rank is a running ballot prefix ----
-    const int th = nini > 0 ? G.ini_th : G.min_th;
-    uint32_t *out = cell_kp + out_cell * G.slot_cap;
-    int total = 0;
+    // ---- 5. emission: the list is row-major already (every compaction above is stable) ----
     for (int i0 = 0; i0 < nfin; i0 += 64) {
         const int i = i0 + lane;
-        const uint32_t key = i < nfin ? sfinal[i] : 0;
-        const bool ok = i < nfin && (int)(key & 0xff) >= th;
-        const unsigned long long mok = __ballot(ok);
-        const int rank = total + lane_prefix(mok);
-        if (ok && rank < G.slot_cap) {
-            const int y = (int)(key >> 15), col = (int)((key >> 8) & 127);
+        const bool ok = i < nfin && i < G.slot_cap;
+        if (ok) {
+            const unsigned short e = slist[i];
+            const int y = e >> 7, col = e & 127;
+            const uint32_t v = score8[__mul24(y + 1, SS) + (col - c_lo + 1)];
             // keypoint relative to (minBorderX, minBorderY): FAST coords + cell offset
             const uint32_t kx = (uint32_t)(col - 4 - a + cd.offx), ky = (uint32_t)(y + 3 + cd.offy);
-            out[rank] = kx | (ky << 12) | ((key & 0xffu) << 24);
+            out[i] = kx | (ky << 12) | (v << 24);
         }
-        total += __popcll(mok);
     }
+    total = nfin;
+    break;
+  }
     if (lane == 0) cell_cnt[out_cell] = min(total, G.slot_cap);
 }
 
@@ -1302,8 +1304,8 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         F.scoreW = (mdw + 2 + 3) >> 2;                     // the score map has its own, tighter row stride (LDS bytes decide
         F.score_words = (mdh + 2) * F.scoreW;              // how many cells a CU holds: 5,340 B -> 4,7xx B = 29 -> 32 per CU)
         F.list_words = (mdw * mdh + 1) / 2 + 1;           // uint16 list: every pixel may pass the pre-test
-        F.final_in_img = (slot_cap + 64 <= F.img_words) ? 1 : 0;
-        e->fast_lds_bytes = (F.img_words + F.score_words + F.list_words + (F.final_in_img ? 0 : slot_cap + 64)) * 4;
+        F.final_in_img = 0;                               // (unused: the NMS survivors stay in the list)
+        e->fast_lds_bytes = (F.img_words + F.score_words + F.list_words) * 4;
         if (F.strideW * 4 > 127 || msh * F.strideW >= 8192) { set_error("cell geometry exceeds the FAST kernel limits"); return ORBHIP_E_SIZE; }
     }
     G.frame_bytes = off;
