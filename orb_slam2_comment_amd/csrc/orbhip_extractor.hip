@@ -548,6 +548,244 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 }
 
 // ---------------------------------------------------------------------------
+// K2+K3, second formulation (same results, about half the vector instructions).  Still one
+// wavefront per reference cell; what changed:
+//  * the LDS row stride SW is a template parameter, so every LDS access of the hot loops is
+//    "one base register + immediate offset";
+//  * staging: lane = (row mod RPI, dword column), the row advance is scalar, no index division;
+//  * dense pre-test on packed uint16 WITHOUT unpacking: a dword of four pixels is read as two
+//    uint16 lanes whose high bytes are pixels 1 and 3 -- the low byte only perturbs the value
+//    by < 1 gray level, which can make the filter pass a non-corner (it is re-checked exactly
+//    by the score) but never drop one; pixels 0 and 2 use the same dwords masked with
+//    0x00ff00ff (exact).  Saturating add/sub give v+t / v-t, the eight comparisons write lane
+//    masks directly (v_cmp -> SGPR pair), so the survivor compaction is mask arithmetic on
+//    the scalar unit plus one v_mbcnt chain;
+//  * score: a survivor's polarity is known from its compass pixels (a 9-arc holds one pixel of
+//    every opposite pair), so the min/max network runs once on sign-selected differences;
+//    the rare pixel that passes the compass test for both polarities (0.3 % of the survivors)
+//    takes a second pass under a wave-uniform branch.  Exactness: brighter and darker arcs of
+//    9 cannot coexist on a ring of 16, so at most one polarity exceeds t and the other one is
+//    <= t < S;
+//  * NMS and emission are one loop (a cell that keeps nothing at iniTh has written nothing).
+// ---------------------------------------------------------------------------
+typedef unsigned short u16x2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2_v as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2_v, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2_v v) { return __builtin_bit_cast(uint32_t, v); }
+// full-rate 24-bit multiplies, forced: LLVM folds the mul24 intrinsics back into v_mul_lo_u32 when it cannot
+// bound an operand
+__device__ __forceinline__ uint32_t mulu24(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int madi24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int SW>
+__global__ __launch_bounds__(64) void k_fast_cells2(const uint8_t *__restrict__ pyr, PyrGeom G,
+                                                    const CellDesc *__restrict__ cells,
+                                                    int *__restrict__ cell_cnt,
+                                                    uint32_t *__restrict__ cell_kp, FastLds F)
+{
+    extern __shared__ uint32_t lds[];
+    constexpr int SB = SW * 4;                 // bytes per staged row
+    constexpr int SS = SB - 8;                 // bytes per score-map row (detection width + 2 halo bytes fit: dw + 2 <= sw - 4)
+    constexpr int LPR = SW <= 16 ? 16 : 32;    // lanes per staged row
+    constexpr int RPI = 64 / LPR;              // rows per staging instruction
+    constexpr int U = 10;                      // staging loads in flight per lane
+    uint32_t *simg = lds;                                   // staged sub-image, LDS col 0 = global column gxb - 4
+    uint32_t *sscore = lds + F.img_words;                   // score map with a 1-px zero halo
+    unsigned short *slist = reinterpret_cast<unsigned short *>(sscore + F.score_words);  // (y << 7) | col
+
+    int cell, fr;
+    xcd_remap(cell, fr);
+    const CellDesc cd = cells[cell];
+    const LevelGeom L = G.lv[cd.level];
+    const uint8_t *roi = pyr + (size_t)fr * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
+    const int sw = cd.x1 - cd.x0, sh = cd.y1 - cd.y0;  // sub-image size
+    const int dw = sw - 6, dh = sh - 6;                // detection rectangle
+    const int lane = threadIdx.x;
+    const size_t out_cell = (size_t)fr * G.ncells_total + cell;
+
+    if (dw <= 0 || dh <= 0) {  // cv::FAST on an image narrower than 7 px finds nothing
+        if (lane == 0) cell_cnt[out_cell] = 0;
+        return;
+    }
+    // LDS column of sub-image x: col = x + a + 4 (a = misalignment of x0; the dword on the left holds real pixels)
+    const int a = cd.x0 & 3;
+    const int gxb = cd.x0 - a;
+    {
+        const int c = lane & (LPR - 1), r = lane / LPR;
+        const uint8_t *sb = roi + (ptrdiff_t)cd.y0 * L.pitch + (gxb - 4);
+        const uint32_t voff = (uint32_t)(__mul24(r, L.pitch) + 4 * c);
+        if (c < SW) {
+            for (int r0 = 0; r0 < sh; r0 += RPI * U) {
+                uint32_t v[U];
+                const uint8_t *p = sb + (ptrdiff_t)r0 * L.pitch;
+                // rows up to sh + RPI - 2 are read: they exist (the cell ends >= 13 rows above the end of the padded plane)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (r0 + u * RPI < sh) v[u] = *reinterpret_cast<const uint32_t *>(p + (uint32_t)(u * RPI * L.pitch) + voff);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (r0 + u * RPI < sh) simg[(r0 + u * RPI + r) * SW + c] = v[u];
+            }
+        }
+    }
+    for (int i = lane; i < (dh + 2) * (SS / 4); i += 64) sscore[i] = 0;
+    __syncthreads();
+
+    // column groups: group g covers LDS cols 4g..4g+3; valid centre cols [c_lo, c_hi)
+    const int c_lo = a + 4 + 3, c_hi = c_lo + dw;
+    const int g_lo = c_lo >> 2, g_hi = (c_hi - 1) >> 2;
+    const int ngrp = g_hi - g_lo + 1;
+    const int nwork = ngrp * dh;                        // (row, group) work items, row-major
+    const uint32_t magic = ((1u << 20) + ngrp - 1) / ngrp;   // exact floor(i / ngrp) for i < 4096
+    const int fj = c_lo & 3, lj = (c_hi - 1) & 3;       // first valid pixel of group g_lo, last valid pixel of group g_hi
+    const uint8_t *img8 = reinterpret_cast<const uint8_t *>(simg);
+    uint8_t *score8 = reinterpret_cast<uint8_t *>(sscore);
+    uint32_t *out = cell_kp + out_cell * G.slot_cap;
+    const int kpx = cd.offx - 4 - a, kpy = cd.offy + 3;  // keypoint = (col + kpx, y + kpy) relative to (minBorderX, minBorderY)
+    int total = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        // the reference calls FAST(iniThFAST) first and FAST(minThFAST) only for cells that kept nothing (:809-816)
+        const int tmin = pass ? G.min_th : G.ini_th;
+        const uint32_t To = (uint32_t)tmin * 0x01000100u, Te = (uint32_t)tmin * 0x00010001u;
+        // ---- dense compass pre-test, survivors -> slist in row-major order ----
+        int nsurv = 0;
+        for (int it0 = 0; it0 < nwork; it0 += 64) {
+            const int itr = it0 + lane;
+            const bool live = itr < nwork;
+            const uint32_t it = (uint32_t)min(itr, nwork - 1);
+            const int y = (int)(mulu24(it, magic) >> 20);           // detection row; sub-image row y + 3
+            const int g = madi24(y, -ngrp, (int)it) + g_lo;
+            const uint32_t *p = simg + (madi24(y, SW, g));
+            const uint32_t up = p[0], c0 = p[3 * SW - 1], c1 = p[3 * SW], c2 = p[3 * SW + 1], dn = p[6 * SW];
+            const uint32_t e4 = __builtin_amdgcn_alignbyte(c2, c1, 3);    // ring pixel 4  (x+3)
+            const uint32_t e12 = __builtin_amdgcn_alignbyte(c1, c0, 1);   // ring pixel 12 (x-3)
+            bool kb[4], kd[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {   // h = 0: pixels 1, 3 (high bytes, low byte is noise); h = 1: pixels 0, 2 (exact)
+                const uint32_t mk = h ? 0x00ff00ffu : 0xffffffffu;
+                const u16x2_v v = as_u16x2(c1 & mk), q0 = as_u16x2(dn & mk), q8 = as_u16x2(up & mk),
+                              q4 = as_u16x2(e4 & mk), q12 = as_u16x2(e12 & mk);
+                // a bright arc of 9 holds p0 or p8 and p4 or p12, all brighter than v + t; a dark arc the mirror image
+                const uint32_t A = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(q0, q8), __builtin_elementwise_max(q4, q12)));
+                const uint32_t B = as_u32(__builtin_elementwise_max(__builtin_elementwise_min(q0, q8), __builtin_elementwise_min(q4, q12)));
+                const uint32_t vT = as_u32(__builtin_elementwise_add_sat(v, as_u16x2(h ? Te : To)));
+                const uint32_t vmT = as_u32(__builtin_elementwise_sub_sat(v, as_u16x2(h ? Te : To)));
+                // low word: 16-bit compare; high word: 32-bit compare (the low word only breaks ties -> passes, never drops)
+                kb[1 - h] = (unsigned short)A > (unsigned short)vT;
+                kd[1 - h] = (unsigned short)B < (unsigned short)vmT;
+                kb[3 - h] = A > vT;
+                kd[3 - h] = B < vmT;
+            }
+            // validity of pixel j of this lane's group (only the first / last group of a row is partial): plain mask
+            // arithmetic (bitwise, not && / ||: those become divergent branches)
+            const bool first = g == g_lo, last = g == g_hi;
+            bool k[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool dead = (first & (j < fj)) | (last & (j > lj));
+                k[j] = (kb[j] | kd[j]) & live & !dead;
+            }
+            // ordered append: lane-major, then pixel = row-major (y, x), the order the reference emits keypoints in; every
+            // later compaction is stable, so the final list needs no sorting
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(k[0]), m1 = __builtin_amdgcn_ballot_w64(k[1]),
+                                     m2 = __builtin_amdgcn_ballot_w64(k[2]), m3 = __builtin_amdgcn_ballot_w64(k[3]);
+            int pos = nsurv + lane_prefix(m0) + lane_prefix(m1) + lane_prefix(m2) + lane_prefix(m3);
+            nsurv += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+            const uint32_t ent = (uint32_t)((y << 7) | (g << 2));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (k[j]) slist[pos] = (unsigned short)(ent + j);
+                pos += k[j];
+            }
+        }
+        __syncthreads();
+
+        // ---- score of the survivors; corners at this threshold -> score map + slist (in place) ----
+        int ncorn = 0;
+        for (int i0 = 0; i0 < nsurv; i0 += 64) {
+            const int i = i0 + lane;
+            const bool act = i < nsurv;
+            const unsigned e = slist[min(i, nsurv - 1)];
+            const int y = e >> 7, col = e & 127;
+            const uint8_t *w = img8 + (madi24(y, SB, col) - 3);   // top-left pixel of the 7x7 window
+            const int v = w[3 * SB + 3];
+            int pr[16];
+            pr[0] = w[6 * SB + 3];  pr[1] = w[6 * SB + 4];  pr[2] = w[5 * SB + 5];  pr[3] = w[4 * SB + 6];
+            pr[4] = w[3 * SB + 6];  pr[5] = w[2 * SB + 6];  pr[6] = w[1 * SB + 5];  pr[7] = w[4];
+            pr[8] = w[3];           pr[9] = w[2];           pr[10] = w[1 * SB + 1]; pr[11] = w[2 * SB];
+            pr[12] = w[3 * SB];     pr[13] = w[4 * SB];     pr[14] = w[5 * SB + 1]; pr[15] = w[6 * SB + 2];
+            const int Ab = min(max(pr[0], pr[8]), max(pr[4], pr[12])), Bd = max(min(pr[0], pr[8]), min(pr[4], pr[12]));
+            const bool brc = Ab > v + tmin, dkc = Bd < v - tmin;
+            // not a bright candidate: a bright arc is impossible (<= t), so the dark network alone gives S (or rejects)
+            const int sgn = brc ? 1 : -1, nv = brc ? -v : v;
+            int d[16];
+#pragma unroll
+            for (int kx = 0; kx < 16; ++kx) d[kx] = madi24(pr[kx], sgn, nv);
+            int m3v[16];
+#pragma unroll
+            for (int kx = 0; kx < 16; ++kx) m3v[kx] = min3i(d[kx], d[(kx + 1) & 15], d[(kx + 2) & 15]);
+            int best = -512;
+#pragma unroll
+            for (int kx = 0; kx < 16; kx += 2) {
+                const int q0 = min3i(m3v[kx], m3v[(kx + 3) & 15], m3v[(kx + 6) & 15]);
+                const int q1 = min3i(m3v[kx + 1], m3v[(kx + 4) & 15], m3v[(kx + 7) & 15]);
+                best = max3i(best, q0, q1);
+            }
+            if (__any(brc & dkc)) {   // both polarities pass the compass test: evaluate the dark one as well
+                int M3v[16];
+#pragma unroll
+                for (int kx = 0; kx < 16; ++kx) M3v[kx] = max3i(d[kx], d[(kx + 1) & 15], d[(kx + 2) & 15]);
+                int worst = 512;
+#pragma unroll
+                for (int kx = 0; kx < 16; kx += 2) {
+                    const int q0 = max3i(M3v[kx], M3v[(kx + 3) & 15], M3v[(kx + 6) & 15]);
+                    const int q1 = max3i(M3v[kx + 1], M3v[(kx + 4) & 15], M3v[(kx + 7) & 15]);
+                    worst = min3i(worst, q0, q1);
+                }
+                if (brc & dkc) best = max(best, -worst);
+            }
+            const int sc = best - 1;                  // cornerScore; corner at t <=> S >= t
+            const bool isc = act & (sc >= tmin);
+            if (isc) score8[madi24(y, SS, col) + (SS - c_lo + 1)] = (uint8_t)sc;   // score column = detection x + 1, row y + 1
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(isc);
+            if (isc) slist[ncorn + lane_prefix(m)] = (unsigned short)e;     // write index <= read index: in place is safe
+            ncorn += __popcll(m);
+        }
+        __syncthreads();
+
+        // ---- NMS over the corner list + emission (row-major already) ----
+        int nfin = 0;
+        for (int i0 = 0; i0 < ncorn; i0 += 64) {
+            const int i = i0 + lane;
+            const unsigned e = slist[min(i, ncorn - 1)];
+            const int y = e >> 7, col = e & 127;
+            const uint8_t *s = score8 + (madi24(y, SS, col) - c_lo);   // top-left neighbour
+            const int v = s[SS + 1];
+            const int nb = max3i(max3i(s[0], s[1], s[2]), max3i(s[SS], s[SS + 2], s[2 * SS]), max((int)s[2 * SS + 1], (int)s[2 * SS + 2]));
+            const bool keep = (i < ncorn) & (v > nb);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+            const int pos = nfin + lane_prefix(m);
+            if (keep & (pos < G.slot_cap))
+                out[pos] = (uint32_t)(col + kpx) | ((uint32_t)(y + kpy) << 12) | ((uint32_t)v << 24);
+            nfin += __popcll(m);
+        }
+        total = nfin;
+        if (nfin != 0) break;       // vKeysCell.empty() -> FAST(minThFAST); the score map keeps its valid entries
+        __syncthreads();
+    }
+    if (lane == 0) cell_cnt[out_cell] = min(total, G.slot_cap);
+}
+
+// ---------------------------------------------------------------------------
 // K4: DistributeOctTree (ORBextractor.cc:539-763), one workgroup per (level, frame).
 // Parallel restatement: keys never move, each carries the index of
 // the node that owns it; a pass counts the four children of every expandable node
@@ -1307,6 +1545,16 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         F.final_in_img = 0;                               // (unused: the NMS survivors stay in the list)
         e->fast_lds_bytes = (F.img_words + F.score_words + F.list_words) * 4;
         if (F.strideW * 4 > 127 || msh * F.strideW >= 8192) { set_error("cell geometry exceeds the FAST kernel limits"); return ORBHIP_E_SIZE; }
+        // second formulation (k_fast_cells2<SW>): compile-time row stride, one extra dword on the left of every row
+        FastLds &F2 = e->fast_lds2;
+        F2 = F;
+        const int need = mndw + 1;
+        F2.strideW = need <= 11 ? 11 : need <= 13 ? 13 : need <= 15 ? 15 : need <= 17 ? 17 : 21;
+        if (need > 21) { set_error("cell geometry exceeds the FAST kernel limits"); return ORBHIP_E_SIZE; }
+        F2.img_words = (msh + 3) * F2.strideW;             // staging may run up to 3 rows past the sub-image
+        F2.scoreW = F2.strideW - 2;
+        F2.score_words = (mdh + 2) * F2.scoreW;
+        e->fast_lds2_bytes = (F2.img_words + F2.score_words + F2.list_words) * 4;
     }
     G.frame_bytes = off;
     G.ncells_total = (int)e->cells.size();
@@ -1381,9 +1629,23 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         }
     }
     if (prof) (void)hipEventRecord(ev[1], s);
-    if (G.ncells_total > 0)
+    static const bool fast_v1 = getenv("ORBHIP_FAST_V1") != nullptr;
+    if (G.ncells_total > 0 && (fast_v1 || e->fast_variant == 1))
         hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, batch), dim3(64), (size_t)e->fast_lds_bytes, s, e->d_pyr, G,
                            e->d_cells, e->d_cell_cnt, e->d_cell_kp, e->fast_lds);
+    else if (G.ncells_total > 0) {
+        const dim3 grid(G.ncells_total, batch);
+        const size_t lb = (size_t)e->fast_lds2_bytes;
+#define ORBHIP_FAST2(SWv) hipLaunchKernelGGL(k_fast_cells2<SWv>, grid, dim3(64), lb, s, e->d_pyr, G, e->d_cells, e->d_cell_cnt, e->d_cell_kp, e->fast_lds2)
+        switch (e->fast_lds2.strideW) {
+        case 11: ORBHIP_FAST2(11); break;
+        case 13: ORBHIP_FAST2(13); break;
+        case 15: ORBHIP_FAST2(15); break;
+        case 17: ORBHIP_FAST2(17); break;
+        default: ORBHIP_FAST2(21); break;
+        }
+#undef ORBHIP_FAST2
+    }
     if (prof) (void)hipEventRecord(ev[2], s);
     if (e->octree_maxn == 512)
         hipLaunchKernelGGL(k_octree<512>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
@@ -1746,6 +2008,9 @@ int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *
     *n = k;
     return k > cap ? ORBHIP_E_CAPACITY : ORBHIP_OK;
 }
+
+// development switch (not part of include/orbhip.h): 1 = first formulation of the FAST kernel, 0 = current one
+int orbhip_dev_set_fast_variant(orbhip_extractor *e, int v) { if (!e) return ORBHIP_E_ARG; e->fast_variant = v; return ORBHIP_OK; }
 
 int orbhip_extractor_set_profiling(orbhip_extractor *e, int on)
 {

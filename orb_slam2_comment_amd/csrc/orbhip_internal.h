@@ -44,6 +44,9 @@ struct orbhip_extractor {
     int octree_maxn = 512;
     orbhip::FastLds fast_lds;   // k_fast_cells dynamic LDS carve-up
     int fast_lds_bytes = 0;
+    orbhip::FastLds fast_lds2;  // k_fast_cells2<SW>: strideW is the template argument
+    int fast_lds2_bytes = 0;
+    int fast_variant = 0;       // development switch: 1 = first formulation
     orbhip::CellDesc *d_cells = nullptr;
     orbhip::TileDesc *d_tiles = nullptr;
     short *d_tabs = nullptr;

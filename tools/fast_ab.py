@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Development tool: per-stage HIP-event times of one 64-frame pipeline for kernel variants, interleaved
+rounds in ONE process (cdna_hip_programming.md section 5.4 rule 24).  Variants are the development switches
+exported by liborbhip.so (orbhip_dev_*), never part of the product API.
+
+  python tools/fast_ab.py [--rounds 8] [--frames 64] [--variants 1,0]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--calls", type=int, default=20)
+    ap.add_argument("--variants", default="1,0")
+    ap.add_argument("--size", default="1241x376")
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    args = ap.parse_args()
+    import torch
+    from orb_slam2_comment_amd import ORBextractor
+    from orb_slam2_comment_amd.capi import lib
+    from orb_slam2_comment_amd.synth import synth_frame
+    W, H = (int(v) for v in args.size.split("x"))
+    dev = torch.device("cuda", 0)
+    B = args.frames
+    frames = np.stack([synth_frame(1 + (i // 2) % 8, W, H, shift_xy=(3 * (i % 2), 0)) for i in range(min(B, 16))])
+    frames = np.stack([frames[i % len(frames)] for i in range(B)])
+    d_img = torch.from_numpy(frames).to(dev)
+    ext = ORBextractor(args.nfeatures, 1.2, 8, 20, 7, device=0)
+    ext.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    cap = ext.capacity(H, W)
+    d_k = torch.zeros((B, cap, 7), dtype=torch.int32, device=dev)
+    d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_s = torch.zeros(B, dtype=torch.int32, device=dev)
+    L = lib()
+    variants = [int(v) for v in args.variants.split(",")]
+
+    def run():
+        ext.extract_batch_device(d_img.data_ptr(), B, H, W, d_k.data_ptr(), d_d.data_ptr(), cap, d_n.data_ptr(), d_s.data_ptr())
+
+    ref = None
+    res = {v: [] for v in variants}
+    for v in variants:                         # results must not depend on the variant
+        L.orbhip_dev_set_fast_variant(ext._h, v)
+        run()
+        torch.cuda.synchronize()
+        sig = (d_n.cpu().numpy().copy(), d_d.cpu().numpy().copy(), d_k.cpu().numpy().copy())
+        if ref is None:
+            ref = sig
+        else:
+            n = ref[0]
+            same = np.array_equal(n, sig[0]) and all(np.array_equal(ref[1][b, :n[b]], sig[1][b, :n[b]]) and
+                                                      np.array_equal(ref[2][b, :n[b]], sig[2][b, :n[b]]) for b in range(B))
+            print("variant %d output identical to variant %d: %s" % (v, variants[0], same), file=sys.stderr)
+    for r in range(args.rounds):
+        for v in variants:
+            L.orbhip_dev_set_fast_variant(ext._h, v)
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            ext.set_profiling(True)
+            for _ in range(args.calls):
+                run()
+            torch.cuda.synchronize()
+            res[v].append(ext.stage_times_us())
+            ext.set_profiling(False)
+    out = {}
+    for v in variants:
+        out[str(v)] = {k: {"median": round(float(np.median([r[k] for r in res[v]])), 2),
+                           "min": round(float(np.min([r[k] for r in res[v]])), 2)} for k in res[v][0]}
+    print(json.dumps({"frames": B, "size": args.size, "stage_us": out}))
+
+
+if __name__ == "__main__":
+    main()
