@@ -356,6 +356,81 @@ int orbhip_search_by_projection_points_device(orbhip_matcher *m, int pairs, cons
                                               float min_x, float min_y, float grid_inv_w, float grid_inv_h,
                                               const void *d_q, const void *d_qdesc, const void *d_nq, int qcap,
                                               float nnratio, void *d_assign, void *d_nmatches);
+/* ORBmatcher::SearchForInitialization, device resident and batched (src/ORBmatcher.cc:405-520): pair p matches
+ * F1 = frame f1_first + p*f1_step against F2 = frame f2_first + p*f2_step of the extractor output arrays.
+ * d_prev_matched [pairs][cap][2] float = vbPrevMatched (in/out; reset_prev != 0 first sets it to F1's keypoint
+ * positions, src/Tracking.cc:578-580); outputs d_matches12 [pairs][cap] int32 (vnMatches12) and d_nmatches [pairs].
+ * One wavefront per pair replays the match-stealing loop.  cap <= 4096. */
+int orbhip_search_for_initialization_device(orbhip_matcher *m, int pairs, const void *d_kps, const void *d_desc,
+                                            const void *d_n, int cap, int f1_first, int f1_step, int f2_first,
+                                            int f2_step, float min_x, float min_y, float grid_inv_w, float grid_inv_h,
+                                            int reset_prev, void *d_prev_matched, int window_size, float nnratio,
+                                            int check_ori, void *d_matches12, void *d_nmatches);
+
+/* ---- projection prologues on the device -------------------------------------------
+ * The arithmetic in front of the window search of the two SearchByProjection overloads.  The reference does it with
+ * cv::Mat expressions (CV_32F); the operation order used here is stated in DESIGN.md section 3 (per row
+ * ((r0*x + r1*y) + r2*z) + t in float without contraction; cv::norm / Mat::dot accumulate in double; logf of
+ * MapPoint::PredictScale is a deterministic, correctly rounded log). */
+typedef struct orbhip_camera {
+    float fx, fy, cx, cy, mbf, mb;           /* Frame::fx, fy, cx, cy, mbf, mb (src/Frame.cc:104-112) */
+    float min_x, max_x, min_y, max_y;        /* mnMinX, mnMaxX, mnMinY, mnMaxY */
+    int32_t n_levels;                        /* mnScaleLevels */
+    float log_scale_factor;                  /* mfLogScaleFactor */
+    float scale_factors[ORBHIP_MAX_LEVELS];  /* mvScaleFactors */
+} orbhip_camera;
+#define ORBHIP_POINT_PRESENT 1   /* the map point exists and takes part (frame search: pMP && !mvbOutlier[i];
+                                    frustum: !isBad() and not already matched in this frame) */
+#define ORBHIP_POINT_OBSERVED 2  /* pMP->Observations() > 0 */
+
+/* Prologue of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), src/ORBmatcher.cc:1339-1390:
+ * Tcw / Tlw = top three rows of CurrentFrame.mTcw / LastFrame.mTcw, row-major (12 floats); world [n][3] =
+ * pMP->GetWorldPos() of LastFrame.mvpMapPoints[i]; flags [n] = ORBHIP_POINT_* bits; last_keys = LastFrame.mvKeysUn
+ * (octave: :1379, angle: :1433).  q [n] out, ready for orbhip_search_by_projection_frame with
+ * qdesc = the map points' descriptors.  Host buffers, synchronous. */
+int orbhip_project_last_frame(orbhip_matcher *m, const orbhip_camera *cam, const float *Tcw, const float *Tlw, int n,
+                              const float *world, const uint8_t *flags, const orbhip_keypoint *last_keys, float th,
+                              int mono, orbhip_query *q);
+
+/* Frame::isInFrustum(pMP, viewing_cos_limit) (src/Frame.cc:269-325) with MapPoint::PredictScale
+ * (src/MapPoint.cc:400-418) for n map points of the local map, followed by the window of
+ * SearchByProjection(F, vpMapPoints, th) (src/ORBmatcher.cc:52-69, RadiusByViewingCos :131-137).  world / normal [n][3]
+ * = GetWorldPos() / GetNormal(); max_dist / min_dist [n] = mfMaxDistance / mfMinDistance (the 1.2 / 0.8 factors of
+ * Get{Max,Min}DistanceInvariance are applied here).  q[i].valid = mbTrackInView, u / v / ur / level_aux =
+ * mTrackProjX / mTrackProjY / mTrackProjXR / mnTrackScaleLevel; view_cos [n] (nullable) = mTrackViewCos. */
+int orbhip_frustum_queries(orbhip_matcher *m, const orbhip_camera *cam, const float *Tcw, int n, const float *world,
+                           const float *normal, const float *max_dist, const float *min_dist, const uint8_t *flags,
+                           float viewing_cos_limit, float th, orbhip_query *q, float *view_cos);
+
+/* Device-resident, batched.  Frames live in the extractor's output layout (d_kps [frames][cap] orbhip_keypoint,
+ * d_desc [frames][cap][32], d_n [frames] int32); pair p has CurrentFrame = frame cur_first + p*cur_step and
+ * LastFrame = frame last_first + p*last_step.  d_Tcw / d_Tlw [pairs][12] float; d_world [frames][cap][3] float and
+ * d_flags [frames][cap] uint8 are indexed by the LAST frame (one map point per last-frame keypoint).
+ *
+ * orbhip_project_last_frame_device writes d_q [pairs][cap] orbhip_query and d_nq [pairs] int32 (= the last frame's n).
+ *
+ * orbhip_track_last_frame_device = that prologue + SearchByProjection's search, resolve and rotation cull in one call
+ * (Tracking::TrackWithMotionModel's matching step, src/Tracking.cc:880-885): the queries' descriptors are the last
+ * frame's (the tracked map points were created from / last seen in it); optional d_u_right [frames][cap] float
+ * (indexed by the current frame) and d_taken [pairs][cap] uint8; outputs d_assign [pairs][cap] int32 (last-frame
+ * keypoint index now held by each current keypoint or -1), d_nmatches [pairs] int32.  cap <= 4096. */
+int orbhip_project_last_frame_device(orbhip_matcher *m, int pairs, const orbhip_camera *cam, const void *d_Tcw,
+                                     const void *d_Tlw, const void *d_kps, const void *d_n, int cap, int last_first,
+                                     int last_step, const void *d_world, const void *d_flags, float th, int mono,
+                                     void *d_q, void *d_nq);
+int orbhip_track_last_frame_device(orbhip_matcher *m, int pairs, const orbhip_camera *cam, const void *d_Tcw,
+                                   const void *d_Tlw, const void *d_kps, const void *d_desc, const void *d_n, int cap,
+                                   int cur_first, int cur_step, int last_first, int last_step, const void *d_world,
+                                   const void *d_flags, const void *d_u_right, const void *d_taken, float th, int mono,
+                                   int check_ori, void *d_assign, void *d_nmatches);
+/* Frame::isInFrustum for `frames` frames at once: d_Tcw [frames][12]; the points of frame f are d_world / d_normal
+ * [frames][pcap][3], d_max_dist / d_min_dist [frames][pcap], d_flags [frames][pcap] uint8, d_np [frames] int32.
+ * Outputs d_q [frames][pcap] orbhip_query, d_view_cos [frames][pcap] float (nullable). */
+int orbhip_frustum_queries_device(orbhip_matcher *m, int frames, const orbhip_camera *cam, const void *d_Tcw, int pcap,
+                                  const void *d_np, const void *d_world, const void *d_normal, const void *d_max_dist,
+                                  const void *d_min_dist, const void *d_flags, float viewing_cos_limit, float th,
+                                  void *d_q, void *d_view_cos);
+
 /* Launch on a caller-owned hipStream_t (NULL: the handle's own stream); wait for the handle's stream. */
 int orbhip_matcher_set_stream(orbhip_matcher *m, void *stream);
 int orbhip_matcher_sync(orbhip_matcher *m);

@@ -30,6 +30,13 @@ class Frame(C.Structure):
                 ("scale_factors", C.c_void_p)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float),
+                ("mb", C.c_float), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
+                ("max_y", C.c_float), ("n_levels", C.c_int32), ("log_scale_factor", C.c_float),
+                ("scale_factors", C.c_float * 8)]
+
+
 class Pyramids(C.Structure):
     _fields_ = [("n_levels", C.c_int32), ("left", C.c_void_p), ("right", C.c_void_p),
                 ("step_left", C.c_void_p), ("step_right", C.c_void_p),
@@ -42,10 +49,19 @@ def build():
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
 
 
+_SO_OVERRIDE = None
+
+
+def use_library(path):
+    """bench.py's cpu_baseline leg: load a build of the same source made for the host it runs on."""
+    global _LIB, _SO_OVERRIDE
+    _LIB, _SO_OVERRIDE = None, path
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liborb_oracle.so")
+        so = _SO_OVERRIDE or os.path.join(_HERE, "liborb_oracle.so")
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)
@@ -82,6 +98,14 @@ def lib():
         L.oracle_search_for_initialization.argtypes = [C.POINTER(Frame), C.POINTER(Frame),
                                                        C.c_void_p, C.c_void_p, C.c_int,
                                                        C.c_float, C.c_int]
+        L.oracle_det_logf.restype = C.c_float
+        L.oracle_det_logf.argtypes = [C.c_float]
+        L.oracle_project_last_frame.restype = None
+        L.oracle_project_last_frame.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+        L.oracle_frustum_queries.restype = None
+        L.oracle_frustum_queries.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.oracle_search_by_projection_frame.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p,
                                                         C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_search_by_projection_block.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
@@ -246,6 +270,46 @@ def search_by_projection_frame(cur, queries, qdesc, taken=None, check_ori=True):
     n = lib().oracle_search_by_projection_frame(C.byref(cur), _p(q), _p(qd), len(q), _p(tk),
                                                 _p(out), int(check_ori))
     return n, out[:cur.n].copy()
+
+
+def camera_from(cam):
+    """oracle_camera with the values of an orbhip Camera (same leading layout, 8 scale factors)."""
+    o = Camera()
+    for f, _ in Camera._fields_[:-1]:
+        setattr(o, f, getattr(cam, f))
+    for i in range(8):
+        o.scale_factors[i] = cam.scale_factors[i]
+    return o
+
+
+def det_logf(x):
+    return float(lib().oracle_det_logf(float(x)))
+
+
+def project_last_frame(cam, Tcw, Tlw, world, flags, last_keys, th, mono):
+    Tc = np.ascontiguousarray(np.asarray(Tcw, np.float32)[:3, :4])
+    Tl = np.ascontiguousarray(np.asarray(Tlw, np.float32)[:3, :4])
+    world = np.ascontiguousarray(world, np.float32).reshape(-1, 3)
+    flags = np.ascontiguousarray(flags, np.uint8)
+    keys = np.ascontiguousarray(last_keys, KP_DTYPE)
+    q = np.zeros(len(keys), QUERY_DTYPE)
+    oc = camera_from(cam)
+    lib().oracle_project_last_frame(C.byref(oc), _p(Tc), _p(Tl), len(keys), _p(world), _p(flags), _p(keys), float(th),
+                                    int(mono), _p(q))
+    return q
+
+
+def frustum_queries(cam, Tcw, world, normal, max_dist, min_dist, flags, viewing_cos_limit, th):
+    Tc = np.ascontiguousarray(np.asarray(Tcw, np.float32)[:3, :4])
+    world = np.ascontiguousarray(world, np.float32).reshape(-1, 3)
+    normal = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+    mx, mn = np.ascontiguousarray(max_dist, np.float32), np.ascontiguousarray(min_dist, np.float32)
+    flags = np.ascontiguousarray(flags, np.uint8)
+    q, vc = np.zeros(len(world), QUERY_DTYPE), np.zeros(len(world), np.float32)
+    oc = camera_from(cam)
+    lib().oracle_frustum_queries(C.byref(oc), _p(Tc), len(world), _p(world), _p(normal), _p(mx), _p(mn), _p(flags),
+                                 float(viewing_cos_limit), float(th), _p(q), _p(vc))
+    return q, vc
 
 
 def search_by_projection_block(cur, queries, qdesc, taken=None, max_dist=100, check_ori=True):

@@ -1605,3 +1605,134 @@ int oracle_vocabulary_transform(const oracle_vocabulary *v, const uint8_t *desc,
     }
     return nb;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Projection prologues.  The reference does this arithmetic with cv::Mat expressions on CV_32F matrices; OpenCV is
+ * not on disk, so the operation order is stated here (parity unpinned):
+ *   - 3x3 * 3x1 + 3x1 (Rcw*x3Dw+tcw): per row ((r0*x + r1*y) + r2*z) + t in float, left to right, no contraction
+ *     (cv::gemm's small-matrix path for CV_32F);
+ *   - cv::norm (NORM_L2, CV_32F): squares accumulated in double in element order, sqrt in double, result to float;
+ *   - Mat::dot (CV_32F): products accumulated in double in element order;
+ *   - log(float) of MapPoint::PredictScale is logf; oracle_det_logf stands in for it (correctly rounded except on
+ *     ~1e-8 of the inputs).
+ * ------------------------------------------------------------------------------------------------------------------ */
+float oracle_det_logf(float xf)
+{
+    /* fdlibm e_log.c, general path only */
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (!(xf > 0.0f)) return xf == 0.0f ? -INFINITY : NAN;
+    if (isinf(xf)) return xf;
+    double x = (double)xf;             /* every positive float is a normal double */
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int hx = (int)(bits >> 32);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int i = (hx + 0x95f64) & 0x100000;
+    bits = ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32) | (bits & 0xffffffffu);   /* normalise x or x/2 */
+    memcpy(&x, &bits, 8);
+    k += i >> 20;
+    const double f = x - 1.0;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = (0.5 * f) * f;
+    return (float)(dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f));
+}
+
+static float dot3_row(const float *r, float x, float y, float z, float t)
+{
+    return ((r[0] * x + r[1] * y) + r[2] * z) + t;
+}
+
+/* src/ORBmatcher.cc:1339-1390 */
+void oracle_project_last_frame(const oracle_camera *cam, const float *Tcw, const float *Tlw, int n, const float *world,
+                               const uint8_t *flags, const oracle_kp *last_keys, float th, int mono, oracle_query *q)
+{
+    /* twc = -Rcw.t()*tcw; tlc = Rlw*twc+tlw (:1342-1347): only tlc.z is used */
+    float twc[3];
+    for (int i = 0; i < 3; ++i) twc[i] = -((Tcw[0 + i] * Tcw[3] + Tcw[4 + i] * Tcw[7]) + Tcw[8 + i] * Tcw[11]);
+    const float tlc_z = dot3_row(Tlw + 8, twc[0], twc[1], twc[2], Tlw[11]);
+    const int forward = tlc_z > cam->mb && !mono, backward = -tlc_z > cam->mb && !mono;   /* :1349-1350 */
+    for (int i = 0; i < n; ++i) {
+        memset(&q[i], 0, sizeof(q[i]));
+        if (!(flags[i] & ORACLE_POINT_PRESENT)) continue;          /* pMP && !mvbOutlier[i] */
+        const float *X = world + 3 * i;
+        const float xc = dot3_row(Tcw, X[0], X[1], X[2], Tcw[3]);
+        const float yc = dot3_row(Tcw + 4, X[0], X[1], X[2], Tcw[7]);
+        const float zc = dot3_row(Tcw + 8, X[0], X[1], X[2], Tcw[11]);
+        const float invzc = (float)(1.0 / (double)zc);                /* const float invzc = 1.0/x3Dc.at<float>(2) */
+        if (invzc < 0) continue;
+        const float u = cam->fx * xc * invzc + cam->cx;
+        const float v = cam->fy * yc * invzc + cam->cy;
+        if (u < cam->min_x || u > cam->max_x) continue;
+        if (v < cam->min_y || v > cam->max_y) continue;
+        const int o = last_keys[i].octave;
+        q[i].valid = 1;
+        q[i].u = u; q[i].v = v;
+        q[i].radius = th * cam->scale_factors[o];
+        if (forward) { q[i].min_level = o; q[i].max_level = -1; }
+        else if (backward) { q[i].min_level = 0; q[i].max_level = o; }
+        else { q[i].min_level = o - 1; q[i].max_level = o + 1; }
+        q[i].ur = u - cam->mbf * invzc;
+        q[i].level_aux = o;
+        q[i].angle = last_keys[i].angle;
+        q[i].observed = (flags[i] & ORACLE_POINT_OBSERVED) ? 1 : 0;
+    }
+}
+
+/* src/Frame.cc:269-325, src/MapPoint.cc:400-418, src/ORBmatcher.cc:52-69 + :131-137 */
+void oracle_frustum_queries(const oracle_camera *cam, const float *Tcw, int n, const float *world, const float *normal,
+                            const float *max_dist, const float *min_dist, const uint8_t *flags, float viewing_cos_limit,
+                            float th, oracle_query *q, float *view_cos)
+{
+    float Ow[3];   /* mOw = -mRcw.t()*mtcw, Frame.cc:266 */
+    for (int i = 0; i < 3; ++i) Ow[i] = -((Tcw[0 + i] * Tcw[3] + Tcw[4 + i] * Tcw[7]) + Tcw[8 + i] * Tcw[11]);
+    const int bFactor = th != 1.0;
+    for (int i = 0; i < n; ++i) {
+        memset(&q[i], 0, sizeof(q[i]));
+        if (view_cos) view_cos[i] = 0.0f;
+        if (!(flags[i] & ORACLE_POINT_PRESENT)) continue;
+        const float *P = world + 3 * i;
+        const float PcX = dot3_row(Tcw, P[0], P[1], P[2], Tcw[3]);
+        const float PcY = dot3_row(Tcw + 4, P[0], P[1], P[2], Tcw[7]);
+        const float PcZ = dot3_row(Tcw + 8, P[0], P[1], P[2], Tcw[11]);
+        if (PcZ < 0.0f) continue;
+        const float invz = 1.0f / PcZ;
+        const float u = cam->fx * PcX * invz + cam->cx;
+        const float v = cam->fy * PcY * invz + cam->cy;
+        if (u < cam->min_x || u > cam->max_x) continue;
+        if (v < cam->min_y || v > cam->max_y) continue;
+        const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];   /* MapPoint.cc:370-383 */
+        const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+        const float dist = (float)sqrt(((double)PO[0] * PO[0] + (double)PO[1] * PO[1]) + (double)PO[2] * PO[2]);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float *Pn = normal + 3 * i;
+        const double dot = ((double)PO[0] * Pn[0] + (double)PO[1] * Pn[1]) + (double)PO[2] * Pn[2];
+        const float viewCos = (float)(dot / (double)dist);
+        if (viewCos < viewing_cos_limit) continue;
+        /* PredictScale */
+        const float ratio = max_dist[i] / dist;
+        const float fl = ceilf(oracle_det_logf(ratio) / cam->log_scale_factor);
+        int nScale = fl >= (float)cam->n_levels ? cam->n_levels - 1 : (fl < 0 ? 0 : (int)fl);   /* also tames inf / nan */
+        if (!(fl == fl)) nScale = 0;
+        float r = (double)viewCos > 0.998 ? 2.5f : 4.0f;   /* RadiusByViewingCos */
+        if (bFactor) r *= th;
+        q[i].valid = 1;
+        q[i].u = u; q[i].v = v;
+        q[i].radius = r * cam->scale_factors[nScale];
+        q[i].min_level = nScale - 1; q[i].max_level = nScale;
+        q[i].ur = u - cam->mbf * invz;
+        q[i].level_aux = nScale;
+        q[i].angle = 0.0f;
+        q[i].observed = (flags[i] & ORACLE_POINT_OBSERVED) ? 1 : 0;
+        if (view_cos) view_cos[i] = viewCos;
+    }
+}

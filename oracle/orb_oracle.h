@@ -206,6 +206,34 @@ int oracle_compute_stereo_matches(const oracle_kp *keys_l, const uint8_t *desc_l
                                   const oracle_pyramids *pyr, int n_rows, float mbf, float mb,
                                   float *u_right, float *depth);
 
+/* ---- projection prologues (the part of the two SearchByProjection overloads in front of the window search) ---- */
+/* Frame statics the prologues read (src/Frame.cc:97-121, :58-60) */
+typedef struct {
+    float fx, fy, cx, cy, mbf, mb;
+    float min_x, max_x, min_y, max_y;  /* mnMinX, mnMaxX, mnMinY, mnMaxY */
+    int32_t n_levels;                  /* mnScaleLevels */
+    float log_scale_factor;            /* mfLogScaleFactor */
+    float scale_factors[8];            /* mvScaleFactors */
+} oracle_camera;
+#define ORACLE_POINT_PRESENT 1  /* map point exists and is usable (not an outlier / not bad / not yet matched) */
+#define ORACLE_POINT_OBSERVED 2 /* pMP->Observations() > 0 */
+
+/* deterministic stand-in for logf: fdlibm's log evaluated in IEEE double with separate mul/add/div, rounded once */
+float oracle_det_logf(float x);
+
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), src/ORBmatcher.cc:1339-1390: poses are the top
+ * three rows of mTcw, row-major; world [n][3] = pMP->GetWorldPos() per last-frame keypoint. */
+void oracle_project_last_frame(const oracle_camera *cam, const float *Tcw, const float *Tlw, int n, const float *world,
+                               const uint8_t *flags, const oracle_kp *last_keys, float th, int mono, oracle_query *q);
+
+/* Frame::isInFrustum (src/Frame.cc:269-325) + MapPoint::PredictScale (src/MapPoint.cc:400-418) for n map points, then
+ * the window of SearchByProjection(F, vpMapPoints, th) (src/ORBmatcher.cc:52-69, :131-137).  max_dist / min_dist are
+ * mfMaxDistance / mfMinDistance.  q[i].valid = mbTrackInView; u, v, ur, level_aux = mTrackProjX/Y/XR, mnTrackScaleLevel;
+ * view_cos[i] = mTrackViewCos (written for points in view). */
+void oracle_frustum_queries(const oracle_camera *cam, const float *Tcw, int n, const float *world, const float *normal,
+                            const float *max_dist, const float *min_dist, const uint8_t *flags, float viewing_cos_limit,
+                            float th, oracle_query *q, float *view_cos);
+
 #ifdef __cplusplus
 }
 #endif

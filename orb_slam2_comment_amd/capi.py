@@ -32,6 +32,16 @@ class FrameView(C.Structure):
                 ("scale_factors", C.c_void_p)]
 
 
+class Camera(C.Structure):
+    """orbhip_camera: the Frame statics the projection prologues read."""
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float),
+                ("mb", C.c_float), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
+                ("max_y", C.c_float), ("n_levels", C.c_int32), ("log_scale_factor", C.c_float),
+                ("scale_factors", C.c_float * MAX_LEVELS)]
+
+
+POINT_PRESENT, POINT_OBSERVED = 1, 2
+
 # every symbol include/orbhip.h declares: (name, restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _pi = C.POINTER(C.c_int)
@@ -92,6 +102,16 @@ SYMBOLS = [
                                                       _vp, _i, _i, _vp, _vp]),
     ("orbhip_search_by_projection_points_device", _i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp,
                                                        _vp, _i, _f, _vp, _vp]),
+    ("orbhip_search_for_initialization_device", _i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _f, _i, _vp, _i,
+                                                     _f, _i, _vp, _vp]),
+    ("orbhip_project_last_frame", _i, [_vp, C.POINTER(Camera), _vp, _vp, _i, _vp, _vp, _vp, _f, _i, _vp]),
+    ("orbhip_frustum_queries", _i, [_vp, C.POINTER(Camera), _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
+    ("orbhip_project_last_frame_device", _i, [_vp, _i, C.POINTER(Camera), _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _i,
+                                              _vp, _vp]),
+    ("orbhip_track_last_frame_device", _i, [_vp, _i, C.POINTER(Camera), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp,
+                                            _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
+    ("orbhip_frustum_queries_device", _i, [_vp, _i, C.POINTER(Camera), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp,
+                                           _vp]),
     ("orbhip_matcher_set_stream", _i, [_vp, _vp]),
     ("orbhip_matcher_sync", _i, [_vp]),
     ("orbhip_compute_stereo_matches_device", _i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i,

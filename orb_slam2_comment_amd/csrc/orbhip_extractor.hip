@@ -312,21 +312,6 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
     }
 }
 
-// ---------------------------------------------------------------------------
-// K2+K3: FAST-9/16 + NMS, one WAVEFRONT per reference cell (= one cv::FAST call,
-// ORBextractor.cc:789-829); 64-thread workgroups, so every hand-off below is wave-local.
-//  1. the (wCell+6)x(hCell+6) sub-image is staged in LDS with aligned dword loads;
-//  2. dense compass pre-test at minThFAST (ring pixels 0,4,8,12: an arc of 9 holds at least one
-//     pixel of every opposite pair), 4 px per lane; survivors (~8 % of pixels) are compacted
-//     into an LDS list with wave ballots;
-//  3. the threshold-independent score S = max(dark,bright)-1 (cornerScore<16>) is computed
-//     only for survivors, at full lane occupancy, with min3/max3 networks; pixels with
-//     S >= minThFAST (corners at minTh) go to the score map and a second list;
-//  4. NMS (strict maximum over the 8 neighbours; outside the detection rectangle = 0, like the
-//     reference's zero-initialised score rows) runs over that list only;
-//  5. threshold selection iniThFAST / fallback minThFAST (:812-816) and row-major ordering
-//     by rank counting over the (few) survivors.
-// ---------------------------------------------------------------------------
 constexpr int kSubMax = 72;              // max (wCell+6), (hCell+6)
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
@@ -335,238 +320,32 @@ __device__ __forceinline__ int lane_prefix(unsigned long long m)
 {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
 }
-typedef short i16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ i16x2_t as_i16x2(uint32_t v) { return __builtin_bit_cast(i16x2_t, v); }
-// bytes (b0,b1) / (b2,b3) of a dword zero-extended to two int16 lanes
-__device__ __forceinline__ i16x2_t bytes01(uint32_t v) { return as_i16x2(__builtin_amdgcn_perm(0u, v, 0x0c010c00u)); }
-__device__ __forceinline__ i16x2_t bytes23(uint32_t v) { return as_i16x2(__builtin_amdgcn_perm(0u, v, 0x0c030c02u)); }
-
-__global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, PyrGeom G,
-                                                   const CellDesc *__restrict__ cells,
-                                                   int *__restrict__ cell_cnt,
-                                                   uint32_t *__restrict__ cell_kp, FastLds F)
-{
-    extern __shared__ uint32_t lds[];
-    uint32_t *simg = lds;                                   // staged sub-image
-    uint32_t *sscore = lds + F.img_words;                   // score map, 1-px zero halo rows
-    unsigned short *slist = reinterpret_cast<unsigned short *>(sscore + F.score_words);  // (y<<7)|col
-
-    int cell, fr;
-    xcd_remap(cell, fr);
-    const CellDesc cd = cells[cell];
-    const LevelGeom L = G.lv[cd.level];
-    const uint8_t *roi = pyr + (size_t)fr * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
-    const int sw = cd.x1 - cd.x0, sh = cd.y1 - cd.y0;  // sub-image size
-    const int dw = sw - 6, dh = sh - 6;                // detection rectangle
-    const int lane = threadIdx.x;
-    const size_t out_cell = (size_t)fr * G.ncells_total + cell;
-    const int SW = F.strideW, SB = F.strideW * 4;
-    const int SS = F.scoreW * 4;                        // bytes per score-map row: detection width + 1-px zero halo, dword rounded
-
-    if (dw <= 0 || dh <= 0) {  // cv::FAST on an image narrower than 7 px finds nothing
-        if (lane == 0) cell_cnt[out_cell] = 0;
-        return;
-    }
-    // LDS column of sub-image x: col = x + a + 4 (4-byte left margin, a = misalignment of x0)
-    const int a = cd.x0 & 3;
-    const int gxb = cd.x0 - a;                          // dword-aligned global column of LDS col 4
-    const int ndw = (a + sw + 3) >> 2;                  // dwords per staged row
-    {   // all global loads of a batch are issued before the first LDS store (one latency, not one per row)
-        constexpr int U = 10;
-        const int total = sh * SW;
-        for (int i0 = 0; i0 < total; i0 += 64 * U) {
-            uint32_t v[U];
-            // branch-free: indices are clamped instead of predicated.  Margin / spare dwords receive a copy of a
-            // neighbouring dword; they are only ever read on behalf of centres outside the detection rectangle.
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = min(i0 + u * 64 + lane, total - 1);
-                // i < 8192, div_magic < 2^20, rows and pitch < 2^13: everything fits the full-rate 24-bit multiplier
-                const int y = (int)(__umul24((unsigned)i, (unsigned)F.div_magic) >> 20), wx = min(max(i - __mul24(y, SW), 1), ndw);
-                v[u] = *reinterpret_cast<const uint32_t *>(roi + (uint32_t)(__mul24(cd.y0 + y, L.pitch) + gxb + 4 * (wx - 1)));
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) simg[min(i0 + u * 64 + lane, total - 1)] = v[u];
-        }
-    }
-    for (int i = lane; i < (dh + 2) * F.scoreW; i += 64) sscore[i] = 0;
-    __syncthreads();
-
-    // column groups: group g covers LDS cols 4g..4g+3; valid centre cols [c_lo, c_hi)
-    const int c_lo = a + 4 + 3, c_hi = c_lo + dw;
-    const int g_lo = c_lo >> 2, g_hi = (c_hi - 1) >> 2;
-    const int ngrp = g_hi - g_lo + 1;                   // <= 17
-    const int nwork = ngrp * dh;                        // (row, group) work items, row-major
-    const int magic = ((1 << 20) + ngrp - 1) / ngrp;    // exact floor(i/ngrp) for i < 4096
-    const int list_dummy = F.list_words * 2 - 1;        // last uint16 of the list region: never a real entry
-    const uint32_t vm_first = (0xfu << (c_lo & 3)) & 0xfu;       // valid centres of the first group of a row
-    const uint32_t vm_last = 0xfu >> (3 - ((c_hi - 1) & 3));     // ... and of the last one
-
-    // Two passes instead of one at minThFAST: the reference calls FAST(iniThFAST) first and only cells that keep nothing go
-    // on to FAST(minThFAST) (:809-816).  A keypoint of the first call has S >= iniTh and beats its 8 neighbours' scores;
-    // neighbours that are not corners at iniTh have S < iniTh and cannot suppress it, so the first call needs the scores
-    // of the iniTh corners only -- a fraction of the minTh corners -- and textured cells never look at the rest.
-  uint32_t *out = cell_kp + out_cell * G.slot_cap;
-  int total = 0;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int tmin = pass ? G.min_th : G.ini_th;
-    const i16x2_t T2 = {(short)tmin, (short)tmin};
-    // ---- 2. dense pre-test (packed int16, two pixels per operation), survivors -> slist ----
-    int nsurv = 0;
-    for (int it0 = 0; it0 < nwork; it0 += 64) {
-        const int it = it0 + lane;
-        const int y = (int)(__umul24((unsigned)it, (unsigned)magic) >> 20);   // detection row; sub-image row y+3 (24-bit operands)
-        const int g = g_lo + it - __mul24(y, ngrp);
-        uint32_t keepm = 0;
-        if (it < nwork) {
-            const int rb = __mul24(y, SW) + g;              // dword index of (row y, group g)
-            const uint32_t *p = &simg[rb + 3 * SW - 1];
-            const uint32_t c0 = p[0], c1 = p[1], c2 = p[2];
-            const uint32_t up = simg[rb], dn = simg[rb + 6 * SW];
-            const uint32_t e4 = __builtin_amdgcn_alignbyte(c2, c1, 3);    // ring pixel 4  (x+3): bytes 7..10
-            const uint32_t e12 = __builtin_amdgcn_alignbyte(c1, c0, 1);   // ring pixel 12 (x-3): bytes 1..4
-            uint32_t m[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const i16x2_t v = h ? bytes23(c1) : bytes01(c1);
-                const i16x2_t d0 = (h ? bytes23(dn) : bytes01(dn)) - v, d8 = (h ? bytes23(up) : bytes01(up)) - v;
-                const i16x2_t d4 = (h ? bytes23(e4) : bytes01(e4)) - v, d12 = (h ? bytes23(e12) : bytes01(e12)) - v;
-                // bright arc needs (p0|p8) and (p4|p12) brighter than v+t; dark arc the mirror image
-                const i16x2_t br = __builtin_elementwise_min(__builtin_elementwise_max(d0, d8), __builtin_elementwise_max(d4, d12));
-                const i16x2_t dk = __builtin_elementwise_max(__builtin_elementwise_min(d0, d8), __builtin_elementwise_min(d4, d12));
-                const i16x2_t s1 = T2 - br, s2 = dk + T2;   // negative <=> br > t, dk < -t
-                m[h] = (__builtin_bit_cast(uint32_t, s1) | __builtin_bit_cast(uint32_t, s2)) & 0x80008000u;
-            }
-            keepm = ((m[0] >> 15) & 1u) | ((m[0] >> 30) & 2u) | ((m[1] >> 13) & 4u) | ((m[1] >> 28) & 8u);
-            // centres outside the detection rectangle: only the first / last group of a row is partial
-            keepm &= (g == g_lo ? vm_first : 0xfu) & (g == g_hi ? vm_last : 0xfu);
-        }
-        const uint32_t ent = (uint32_t)((y << 7) | (4 * g));
-        // Ordered append: lane-major, then pixel -- i.e. row-major (y, x), the order the reference emits keypoints in.
-        // Every later compaction is stable, so the final list needs no sorting.  The wave prefix sum of the per-lane
-        // survivor counts (0..4) is three ballots over the bits of the count.
-        const int cnt = __popc(keepm);
-        const unsigned long long p0 = __ballot(cnt & 1), p1 = __ballot(cnt & 2), p2 = __ballot(cnt & 4);
-        int pos = nsurv + lane_prefix(p0) + 2 * lane_prefix(p1) + 4 * lane_prefix(p2);
-        nsurv += __popcll(p0) + 2 * __popcll(p1) + 4 * __popcll(p2);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool pre = (keepm >> j) & 1u;
-            // branch-free: lanes without a survivor write the scratch slot behind the list
-            slist[pre ? pos : list_dummy] = (unsigned short)(ent + j);
-            pos += pre;
-        }
-    }
-    __syncthreads();
-
-    // ---- 3. score of the survivors; corners at minTh -> score map + slist (in place) ----
-    const uint8_t *img8 = reinterpret_cast<const uint8_t *>(simg);
-    uint8_t *score8 = reinterpret_cast<uint8_t *>(sscore);
-    int ncorn = 0;
-    for (int i0 = 0; i0 < nsurv; i0 += 64) {
-        const int i = i0 + lane;
-        bool isc = false;
-        unsigned short e = 0;
-        if (i < nsurv) {
-            e = slist[i];
-            const int y = e >> 7, col = e & 127;
-            const uint8_t *c = img8 + __mul24(y + 3, SB) + col;
-            const int v = c[0];
-            int d[16];
-            d[0] = v - c[3 * SB];       d[1] = v - c[3 * SB + 1];
-            d[2] = v - c[2 * SB + 2];   d[3] = v - c[SB + 3];
-            d[4] = v - c[3];            d[5] = v - c[-SB + 3];
-            d[6] = v - c[-2 * SB + 2];  d[7] = v - c[-3 * SB + 1];
-            d[8] = v - c[-3 * SB];      d[9] = v - c[-3 * SB - 1];
-            d[10] = v - c[-2 * SB - 2]; d[11] = v - c[-SB - 3];
-            d[12] = v - c[-3];          d[13] = v - c[SB - 3];
-            d[14] = v - c[2 * SB - 2];  d[15] = v - c[3 * SB - 1];
-            int m3[16], M3[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                m3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-                M3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-            }
-            int mn9[16], mx9[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                mn9[k] = min3i(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
-                mx9[k] = max3i(M3[k], M3[(k + 3) & 15], M3[(k + 6) & 15]);
-            }
-            int dark = max3i(max3i(mn9[0], mn9[1], mn9[2]), max3i(mn9[3], mn9[4], mn9[5]), max3i(mn9[6], mn9[7], mn9[8]));
-            dark = max3i(dark, max3i(mn9[9], mn9[10], mn9[11]), max3i(mn9[12], mn9[13], max(mn9[14], mn9[15])));
-            int brn = min3i(min3i(mx9[0], mx9[1], mx9[2]), min3i(mx9[3], mx9[4], mx9[5]), min3i(mx9[6], mx9[7], mx9[8]));
-            brn = min3i(brn, min3i(mx9[9], mx9[10], mx9[11]), min3i(mx9[12], mx9[13], min(mx9[14], mx9[15])));
-            const int sc = max(dark, -brn) - 1;       // cornerScore; corner at minTh <=> S >= minTh
-            isc = sc >= tmin;
-            if (isc) score8[__mul24(y + 1, SS) + (col - c_lo + 1)] = (uint8_t)min(sc, 255);   // score column = detection x + 1
-        }
-        const unsigned long long m = __ballot(isc);
-        if (isc) slist[ncorn + lane_prefix(m)] = e;     // write index <= read index: in place is safe
-        ncorn += __popcll(m);
-    }
-    __syncthreads();
-
-    // ---- 4. NMS over the corner list; the survivors stay in the list (in place: write index <= read index) ----
-    int nfin = 0;
-    for (int i0 = 0; i0 < ncorn; i0 += 64) {
-        const int i = i0 + lane;
-        bool keep = false;
-        unsigned short e = 0;
-        if (i < ncorn) {
-            e = slist[i];
-            const int y = e >> 7, col = e & 127;
-            const uint8_t *s = score8 + __mul24(y + 1, SS) + (col - c_lo + 1);
-            const int v = s[0];
-            keep = v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] &&
-                   v > s[SS - 1] && v > s[SS] && v > s[SS + 1];
-        }
-        const unsigned long long m = __ballot(keep);
-        if (keep) slist[nfin + lane_prefix(m)] = e;
-        nfin += __popcll(m);
-    }
-    __syncthreads();
-    if (nfin == 0 && pass == 0) continue;       // vKeysCell.empty() -> FAST(minThFAST); the score map keeps valid entries
-
-    // ---- 5. emission: the list is row-major already (every compaction above is stable) ----
-    for (int i0 = 0; i0 < nfin; i0 += 64) {
-        const int i = i0 + lane;
-        const bool ok = i < nfin && i < G.slot_cap;
-        if (ok) {
-            const unsigned short e = slist[i];
-            const int y = e >> 7, col = e & 127;
-            const uint32_t v = score8[__mul24(y + 1, SS) + (col - c_lo + 1)];
-            // keypoint relative to (minBorderX, minBorderY): FAST coords + cell offset
-            const uint32_t kx = (uint32_t)(col - 4 - a + cd.offx), ky = (uint32_t)(y + 3 + cd.offy);
-            out[i] = kx | (ky << 12) | (v << 24);
-        }
-    }
-    total = nfin;
-    break;
-  }
-    if (lane == 0) cell_cnt[out_cell] = min(total, G.slot_cap);
-}
 
 // ---------------------------------------------------------------------------
-// K2+K3, second formulation (same results, about half the vector instructions).  Still one
-// wavefront per reference cell; what changed:
-//  * the LDS row stride SW is a template parameter, so every LDS access of the hot loops is
-//    "one base register + immediate offset";
-//  * staging: lane = (row mod RPI, dword column), the row advance is scalar, no index division;
-//  * dense pre-test on packed uint16 WITHOUT unpacking: a dword of four pixels is read as two
-//    uint16 lanes whose high bytes are pixels 1 and 3 -- the low byte only perturbs the value
-//    by < 1 gray level, which can make the filter pass a non-corner (it is re-checked exactly
-//    by the score) but never drop one; pixels 0 and 2 use the same dwords masked with
-//    0x00ff00ff (exact).  Saturating add/sub give v+t / v-t, the eight comparisons write lane
-//    masks directly (v_cmp -> SGPR pair), so the survivor compaction is mask arithmetic on
-//    the scalar unit plus one v_mbcnt chain;
-//  * score: a survivor's polarity is known from its compass pixels (a 9-arc holds one pixel of
-//    every opposite pair), so the min/max network runs once on sign-selected differences;
-//    the rare pixel that passes the compass test for both polarities (0.3 % of the survivors)
-//    takes a second pass under a wave-uniform branch.  Exactness: brighter and darker arcs of
-//    9 cannot coexist on a ring of 16, so at most one polarity exceeds t and the other one is
-//    <= t < S;
-//  * NMS and emission are one loop (a cell that keeps nothing at iniTh has written nothing).
+// K2+K3: FAST-9/16 + NMS, one WAVEFRONT per reference cell (= the reference's cv::FAST call(s) for
+// that cell, ORBextractor.cc:789-829); 64-thread workgroups, every hand-off is wave-local.
+//  1. staging: the (wCell+6)x(hCell+6) sub-image goes to LDS as aligned dwords; lane = (row mod RPI,
+//     dword column), the row advance is scalar.  The LDS row stride SW is a template parameter, so
+//     every LDS access of the hot loops is "one base register + immediate offset".
+//  2. dense compass pre-test at the pass threshold (ring pixels 0,4,8,12: an arc of 9 holds one pixel
+//     of every opposite pair), 4 px per lane, on packed uint16 WITHOUT unpacking: a dword of four
+//     pixels is read as two uint16 lanes whose high bytes are pixels 1 and 3 -- the low byte only
+//     perturbs the value by < 1 gray level, which can let a non-corner through (the score re-checks
+//     exactly) but never drops one; pixels 0 and 2 use the same dwords masked with 0x00ff00ff
+//     (exact).  Saturating add/sub give v+t / v-t; the eight comparisons write lane masks directly
+//     (v_cmp -> SGPR pair), the masks are combined on the scalar unit, and the ordered survivor
+//     compaction is one v_mbcnt chain + carry-in adds.
+//  3. the threshold-independent score S = max(dark,bright)-1 (cornerScore<16>) only for survivors:
+//     a survivor's polarity follows from its compass pixels, so the min3 network runs once on
+//     sign-selected differences; a pixel that passes the compass test for both polarities (0.3 %
+//     of the survivors) takes the max3 network too, under a wave-uniform branch.  Exactness: a
+//     brighter and a darker arc of 9 cannot coexist on a ring of 16, so at most one polarity
+//     exceeds t and the other one is <= t < S.
+//  4. NMS (strict maximum over the 8 neighbours; outside the detection rectangle = 0, like the
+//     reference's zero-initialised score rows) over the corner list, fused with the emission.
+//  5. pass 0 runs at iniThFAST; a cell that keeps nothing repeats 2-4 at minThFAST (:809-816).
+// Every compaction is stable and lanes walk the cell row-major, so the emitted list is already in
+// the reference's order.
 // ---------------------------------------------------------------------------
 typedef unsigned short u16x2_v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2_v as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2_v, v); }
@@ -585,12 +364,43 @@ __device__ __forceinline__ int madi24(int a, int b, int c)
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// same with a wave-uniform second factor held in an SGPR (one constant-bus operand)
+__device__ __forceinline__ uint32_t mulu24_s(uint32_t a, uint32_t sb)
+{
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %2, %1" : "=v"(r) : "v"(a), "s"(sb));
+    return r;
+}
+__device__ __forceinline__ int madi24_s(int a, int sb, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(sb), "v"(c));
+    return r;
+}
+// x + (this lane's bit of a lane mask): the mask is the carry-in, one instruction
+__device__ __forceinline__ int add_lane_bit(int x, unsigned long long mask)
+{
+    int r;
+    asm("v_addc_co_u32 %0, vcc, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask) : "vcc");
+    return r;
+}
 
-template <int SW>
-__global__ __launch_bounds__(64) void k_fast_cells2(const uint8_t *__restrict__ pyr, PyrGeom G,
-                                                    const CellDesc *__restrict__ cells,
-                                                    int *__restrict__ cell_cnt,
-                                                    uint32_t *__restrict__ cell_kp, FastLds F)
+// Diagnostic build only (STAMPS = true, never launched by the product path): per-phase s_memtime sums of all waves,
+// read by tools/fast_ab.py through orbhip_dev_fast_stamps.  Shares, not lengths, are meaningful (the stamps fence).
+__device__ unsigned long long g_fast_stamps[8];
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <int SW, bool STAMPS = false>
+__global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, const FastCell *__restrict__ cells,
+                                                    int *__restrict__ cell_cnt, uint32_t *__restrict__ cell_kp,
+                                                    FastParams P)
 {
     extern __shared__ uint32_t lds[];
     constexpr int SB = SW * 4;                 // bytes per staged row
@@ -599,76 +409,93 @@ __global__ __launch_bounds__(64) void k_fast_cells2(const uint8_t *__restrict__ 
     constexpr int RPI = 64 / LPR;              // rows per staging instruction
     constexpr int U = 10;                      // staging loads in flight per lane
     uint32_t *simg = lds;                                   // staged sub-image, LDS col 0 = global column gxb - 4
-    uint32_t *sscore = lds + F.img_words;                   // score map with a 1-px zero halo
-    unsigned short *slist = reinterpret_cast<unsigned short *>(sscore + F.score_words);  // (y << 7) | col
+    uint32_t *sscore = simg + P.img_words;                   // score map with a 1-px zero halo
+    unsigned short *slist = reinterpret_cast<unsigned short *>(sscore + P.score_words);  // (y << 7) | col
 
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define FAST_STAMP(i) do { if constexpr (STAMPS) { const unsigned long long t_ = stamp_now(); tacc[i] += t_ - tprev; tprev = t_; } } while (0)
+    if constexpr (STAMPS) tprev = stamp_now();
+    // XCD-aware (cell, frame) of this wavefront (see xcd_remap); the division by the cell count is a multiply by the
+    // host-computed reciprocal (exact for lin2 < 2^32 / ncells, checked on the host), all on the scalar unit
     int cell, fr;
-    xcd_remap(cell, fr);
-    const CellDesc cd = cells[cell];
-    const LevelGeom L = G.lv[cd.level];
-    const uint8_t *roi = pyr + (size_t)fr * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
-    const int sw = cd.x1 - cd.x0, sh = cd.y1 - cd.y0;  // sub-image size
-    const int dw = sw - 6, dh = sh - 6;                // detection rectangle
+    {
+        const unsigned T = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned q = T >> 3, r = T & 7, x = lin & 7;
+        const unsigned lin2 = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3);
+        fr = (int)__umulhi(lin2, P.rcp_cells);
+        cell = (int)(lin2 - (unsigned)fr * gridDim.x);
+    }
     const int lane = threadIdx.x;
-    const size_t out_cell = (size_t)fr * G.ncells_total + cell;
+    // everything this cell needs is one 32-byte record, fetched with one scalar load (constant address space)
+    typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+    const u32x8_t raw = *reinterpret_cast<const __attribute__((address_space(4))) u32x8_t *>(reinterpret_cast<uintptr_t>(cells + cell));
+    const FastCell cd = __builtin_bit_cast(FastCell, raw);
+    const int sh = cd.sh, dw = cd.sw - 6, dh = cd.sh - 6;   // sub-image rows; detection rectangle
+    const int pitch = cd.pitch;
+    const size_t out_cell = (size_t)fr * P.ncells_total + cell;
 
     if (dw <= 0 || dh <= 0) {  // cv::FAST on an image narrower than 7 px finds nothing
         if (lane == 0) cell_cnt[out_cell] = 0;
         return;
     }
-    // LDS column of sub-image x: col = x + a + 4 (a = misalignment of x0; the dword on the left holds real pixels)
-    const int a = cd.x0 & 3;
-    const int gxb = cd.x0 - a;
+    FAST_STAMP(0);   // prologue
+    if (P.dev == 3) { if (lane == 0) cell_cnt[out_cell] = 0; return; }   // development: launch floor
+    // LDS column of sub-image x: col = x + a + 4 (a = misalignment of x0; the dword on the left holds real pixels).
+    // Lane = (row mod RPI, dword column); a batch is U row groups, all loads issued before the first LDS store.  Row
+    // groups past the sub-image re-read its last rows (scalar clamp) into LDS rows that nothing looks at.
     {
         const int c = lane & (LPR - 1), r = lane / LPR;
-        const uint8_t *sb = roi + (ptrdiff_t)cd.y0 * L.pitch + (gxb - 4);
-        const uint32_t voff = (uint32_t)(__mul24(r, L.pitch) + 4 * c);
+        const uint8_t *sb = pyr + (size_t)fr * P.frame_bytes + cd.src_off;
+        const uint32_t voff = (uint32_t)(__mul24(r, pitch) + 4 * c);
+        uint32_t *sdst = simg + (r * SW + c);
         if (c < SW) {
             for (int r0 = 0; r0 < sh; r0 += RPI * U) {
                 uint32_t v[U];
-                const uint8_t *p = sb + (ptrdiff_t)r0 * L.pitch;
-                // rows up to sh + RPI - 2 are read: they exist (the cell ends >= 13 rows above the end of the padded plane)
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    if (r0 + u * RPI < sh) v[u] = *reinterpret_cast<const uint32_t *>(p + (uint32_t)(u * RPI * L.pitch) + voff);
+                    v[u] = *reinterpret_cast<const uint32_t *>(sb + (uint32_t)(min(r0 + u * RPI, sh - 1) * pitch) + voff);
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (r0 + u * RPI < sh) simg[(r0 + u * RPI + r) * SW + c] = v[u];
+                for (int u = 0; u < U; ++u) sdst[(r0 + u * RPI) * SW] = v[u];
             }
         }
     }
     for (int i = lane; i < (dh + 2) * (SS / 4); i += 64) sscore[i] = 0;
     __syncthreads();
+    FAST_STAMP(1);   // staging (global -> LDS) + score-map clear
+    if (P.dev == 4) { if (lane == 0) cell_cnt[out_cell] = (int)simg[lane] & 0; return; }   // development: staging floor
 
     // column groups: group g covers LDS cols 4g..4g+3; valid centre cols [c_lo, c_hi)
+    const int a = cd.a;
     const int c_lo = a + 4 + 3, c_hi = c_lo + dw;
     const int g_lo = c_lo >> 2, g_hi = (c_hi - 1) >> 2;
     const int ngrp = g_hi - g_lo + 1;
     const int nwork = ngrp * dh;                        // (row, group) work items, row-major
-    const uint32_t magic = ((1u << 20) + ngrp - 1) / ngrp;   // exact floor(i / ngrp) for i < 4096
+    const uint32_t magic = cd.magic;                    // ceil(2^20 / ngrp): exact floor(i / ngrp) for i < 4096
     const int fj = c_lo & 3, lj = (c_hi - 1) & 3;       // first valid pixel of group g_lo, last valid pixel of group g_hi
     const uint8_t *img8 = reinterpret_cast<const uint8_t *>(simg);
     uint8_t *score8 = reinterpret_cast<uint8_t *>(sscore);
-    uint32_t *out = cell_kp + out_cell * G.slot_cap;
-    const int kpx = cd.offx - 4 - a, kpy = cd.offy + 3;  // keypoint = (col + kpx, y + kpy) relative to (minBorderX, minBorderY)
+    uint32_t *out = cell_kp + out_cell * P.slot_cap;
+    const int kpx = cd.kpx, kpy = cd.kpy;               // keypoint = (col + kpx, y + kpy) relative to (minBorderX, minBorderY)
     int total = 0;
     for (int pass = 0; pass < 2; ++pass) {
         // the reference calls FAST(iniThFAST) first and FAST(minThFAST) only for cells that kept nothing (:809-816)
-        const int tmin = pass ? G.min_th : G.ini_th;
+        const int tmin = pass ? P.min_th : P.ini_th;
         const uint32_t To = (uint32_t)tmin * 0x01000100u, Te = (uint32_t)tmin * 0x00010001u;
         // ---- dense compass pre-test, survivors -> slist in row-major order ----
         int nsurv = 0;
         for (int it0 = 0; it0 < nwork; it0 += 64) {
+            // items past the end (last iteration) recompute the last item and are masked out of the result
             const int itr = it0 + lane;
-            const bool live = itr < nwork;
             const uint32_t it = (uint32_t)min(itr, nwork - 1);
-            const int y = (int)(mulu24(it, magic) >> 20);           // detection row; sub-image row y + 3
-            const int g = madi24(y, -ngrp, (int)it) + g_lo;
+            const int y = (int)(mulu24_s(it, magic) >> 20);           // detection row; sub-image row y + 3
+            const int g = madi24_s(y, -ngrp, (int)it) + g_lo;
             const uint32_t *p = simg + (madi24(y, SW, g));
             const uint32_t up = p[0], c0 = p[3 * SW - 1], c1 = p[3 * SW], c2 = p[3 * SW + 1], dn = p[6 * SW];
             const uint32_t e4 = __builtin_amdgcn_alignbyte(c2, c1, 3);    // ring pixel 4  (x+3)
             const uint32_t e12 = __builtin_amdgcn_alignbyte(c1, c0, 1);   // ring pixel 12 (x-3)
-            bool kb[4], kd[4];
+            // every comparison is ballot()ed on its own (v_cmp writes the lane mask directly) and the masks are combined as
+            // 64-bit integers on the scalar unit; combining bools first makes the compiler round-trip through VGPRs
+            unsigned long long mb[4], md[4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {   // h = 0: pixels 1, 3 (high bytes, low byte is noise); h = 1: pixels 0, 2 (exact)
                 const uint32_t mk = h ? 0x00ff00ffu : 0xffffffffu;
@@ -680,34 +507,35 @@ __global__ __launch_bounds__(64) void k_fast_cells2(const uint8_t *__restrict__ 
                 const uint32_t vT = as_u32(__builtin_elementwise_add_sat(v, as_u16x2(h ? Te : To)));
                 const uint32_t vmT = as_u32(__builtin_elementwise_sub_sat(v, as_u16x2(h ? Te : To)));
                 // low word: 16-bit compare; high word: 32-bit compare (the low word only breaks ties -> passes, never drops)
-                kb[1 - h] = (unsigned short)A > (unsigned short)vT;
-                kd[1 - h] = (unsigned short)B < (unsigned short)vmT;
-                kb[3 - h] = A > vT;
-                kd[3 - h] = B < vmT;
+                mb[1 - h] = __builtin_amdgcn_ballot_w64((unsigned short)A > (unsigned short)vT);
+                md[1 - h] = __builtin_amdgcn_ballot_w64((unsigned short)B < (unsigned short)vmT);
+                mb[3 - h] = __builtin_amdgcn_ballot_w64(A > vT);
+                md[3 - h] = __builtin_amdgcn_ballot_w64(B < vmT);
             }
-            // validity of pixel j of this lane's group (only the first / last group of a row is partial): plain mask
-            // arithmetic (bitwise, not && / ||: those become divergent branches)
-            const bool first = g == g_lo, last = g == g_hi;
-            bool k[4];
+            // validity of pixel j of this lane's group: only the first / last group of a row is partial
+            const unsigned long long mlive = __builtin_amdgcn_ballot_w64(itr < nwork),
+                                     mfirst = __builtin_amdgcn_ballot_w64(g == g_lo), mlast = __builtin_amdgcn_ballot_w64(g == g_hi);
+            unsigned long long m[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool dead = (first & (j < fj)) | (last & (j > lj));
-                k[j] = (kb[j] | kd[j]) & live & !dead;
-            }
+            for (int j = 0; j < 4; ++j)
+                m[j] = (mb[j] | md[j]) & mlive & ~((j < fj ? mfirst : 0ull) | (j > lj ? mlast : 0ull));
             // ordered append: lane-major, then pixel = row-major (y, x), the order the reference emits keypoints in; every
             // later compaction is stable, so the final list needs no sorting
-            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(k[0]), m1 = __builtin_amdgcn_ballot_w64(k[1]),
-                                     m2 = __builtin_amdgcn_ballot_w64(k[2]), m3 = __builtin_amdgcn_ballot_w64(k[3]);
-            int pos = nsurv + lane_prefix(m0) + lane_prefix(m1) + lane_prefix(m2) + lane_prefix(m3);
-            nsurv += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+            int pos[4];
+            pos[0] = __builtin_amdgcn_mbcnt_hi((unsigned)(m[0] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[0], (unsigned)nsurv));
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+                pos[0] = __builtin_amdgcn_mbcnt_hi((unsigned)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[j], (unsigned)pos[0]));
+#pragma unroll
+            for (int j = 1; j < 4; ++j) pos[j] = add_lane_bit(pos[j - 1], m[j - 1]);
+            nsurv += __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
             const uint32_t ent = (uint32_t)((y << 7) | (g << 2));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (k[j]) slist[pos] = (unsigned short)(ent + j);
-                pos += k[j];
-            }
+            for (int j = 0; j < 4; ++j)
+                if (__builtin_amdgcn_inverse_ballot_w64(m[j])) slist[pos[j]] = (unsigned short)(ent + j);
         }
         __syncthreads();
+        FAST_STAMP(2);   // dense pre-test + compaction
 
         // ---- score of the survivors; corners at this threshold -> score map + slist (in place) ----
         int ncorn = 0;
@@ -754,13 +582,15 @@ __global__ __launch_bounds__(64) void k_fast_cells2(const uint8_t *__restrict__ 
                 if (brc & dkc) best = max(best, -worst);
             }
             const int sc = best - 1;                  // cornerScore; corner at t <=> S >= t
-            const bool isc = act & (sc >= tmin);
-            if (isc) score8[madi24(y, SS, col) + (SS - c_lo + 1)] = (uint8_t)sc;   // score column = detection x + 1, row y + 1
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(isc);
-            if (isc) slist[ncorn + lane_prefix(m)] = (unsigned short)e;     // write index <= read index: in place is safe
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(sc >= tmin) & __builtin_amdgcn_ballot_w64(act);
+            if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                score8[madi24(y, SS, col) + (SS - c_lo + 1)] = (uint8_t)sc;   // score column = detection x + 1, row y + 1
+                slist[ncorn + lane_prefix(m)] = (unsigned short)e;            // write index <= read index: in place is safe
+            }
             ncorn += __popcll(m);
         }
         __syncthreads();
+        FAST_STAMP(3);   // score network
 
         // ---- NMS over the corner list + emission (row-major already) ----
         int nfin = 0;
@@ -771,18 +601,26 @@ __global__ __launch_bounds__(64) void k_fast_cells2(const uint8_t *__restrict__ 
             const uint8_t *s = score8 + (madi24(y, SS, col) - c_lo);   // top-left neighbour
             const int v = s[SS + 1];
             const int nb = max3i(max3i(s[0], s[1], s[2]), max3i(s[SS], s[SS + 2], s[2 * SS]), max((int)s[2 * SS + 1], (int)s[2 * SS + 2]));
-            const bool keep = (i < ncorn) & (v > nb);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(i < ncorn) & __builtin_amdgcn_ballot_w64(v > nb);
             const int pos = nfin + lane_prefix(m);
-            if (keep & (pos < G.slot_cap))
+            if (__builtin_amdgcn_inverse_ballot_w64(m & __builtin_amdgcn_ballot_w64(pos < P.slot_cap)))
                 out[pos] = (uint32_t)(col + kpx) | ((uint32_t)(y + kpy) << 12) | ((uint32_t)v << 24);
             nfin += __popcll(m);
         }
         total = nfin;
+        FAST_STAMP(4);   // NMS + emission
         if (nfin != 0) break;       // vKeysCell.empty() -> FAST(minThFAST); the score map keeps its valid entries
         __syncthreads();
     }
-    if (lane == 0) cell_cnt[out_cell] = min(total, G.slot_cap);
+    if (lane == 0) cell_cnt[out_cell] = min(total, P.slot_cap);
+    if constexpr (STAMPS) {
+        if (lane == 0 && (cell & 63) == 0) {   // one wave in 64 reports (78,080 waves on six addresses would serialise)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) atomicAdd(&g_fast_stamps[i], tacc[i]);
+            atomicAdd(&g_fast_stamps[7], 1ull);
+        }
+    }
+#undef FAST_STAMP
 }
 
 // ---------------------------------------------------------------------------
@@ -1400,8 +1238,8 @@ static void drop_graph(orbhip_extractor *e)
 static void free_geometry(orbhip_extractor *e)
 {
     drop_graph(e);
-    (void)hipFree(e->d_cells); (void)hipFree(e->d_tiles); (void)hipFree(e->d_tabs);
-    e->d_cells = nullptr; e->d_tiles = nullptr; e->d_tabs = nullptr;
+    (void)hipFree(e->d_cells); (void)hipFree(e->d_cells2); (void)hipFree(e->d_tiles); (void)hipFree(e->d_tabs);
+    e->d_cells = nullptr; e->d_cells2 = nullptr; e->d_tiles = nullptr; e->d_tabs = nullptr;
     e->bound = false;
 }
 static void free_batch(orbhip_extractor *e)
@@ -1535,26 +1373,38 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
             mdw = std::max(mdw, c.x1 - c.x0 - 6);
             mndw = std::max(mndw, ((c.x0 & 3) + (c.x1 - c.x0) + 3) >> 2);
         }
-        FastLds &F = e->fast_lds;
-        F.strideW = (mndw + 2) | 1;                       // margin + spare, odd: rows rotate over the LDS banks
-        F.div_magic = ((1 << 20) + F.strideW - 1) / F.strideW;
-        F.img_words = msh * F.strideW;
-        F.scoreW = (mdw + 2 + 3) >> 2;                     // the score map has its own, tighter row stride (LDS bytes decide
-        F.score_words = (mdh + 2) * F.scoreW;              // how many cells a CU holds: 5,340 B -> 4,7xx B = 29 -> 32 per CU)
-        F.list_words = (mdw * mdh + 1) / 2 + 1;           // uint16 list: every pixel may pass the pre-test
-        F.final_in_img = 0;                               // (unused: the NMS survivors stay in the list)
-        e->fast_lds_bytes = (F.img_words + F.score_words + F.list_words) * 4;
-        if (F.strideW * 4 > 127 || msh * F.strideW >= 8192) { set_error("cell geometry exceeds the FAST kernel limits"); return ORBHIP_E_SIZE; }
-        // second formulation (k_fast_cells2<SW>): compile-time row stride, one extra dword on the left of every row
-        FastLds &F2 = e->fast_lds2;
-        F2 = F;
+        FastLds &F2 = e->fast_lds;
+        // compile-time row stride (odd: rows rotate over the LDS banks): staged dwords + one real dword on the left
         const int need = mndw + 1;
         F2.strideW = need <= 11 ? 11 : need <= 13 ? 13 : need <= 15 ? 15 : need <= 17 ? 17 : 21;
         if (need > 21) { set_error("cell geometry exceeds the FAST kernel limits"); return ORBHIP_E_SIZE; }
-        F2.img_words = (msh + 3) * F2.strideW;             // staging may run up to 3 rows past the sub-image
         F2.scoreW = F2.strideW - 2;
         F2.score_words = (mdh + 2) * F2.scoreW;
-        e->fast_lds2_bytes = (F2.img_words + F2.score_words + F2.list_words) * 4;
+        F2.list_words = (mdw * mdh + 1) / 2 + 1;           // uint16 list: every pixel may pass the pre-test
+        // staging batches write whole row groups: round the image rows up to what they touch
+        {
+            const int lpr = F2.strideW <= 16 ? 16 : 32, rpi = 64 / lpr, rows_batch = rpi * 10;
+            const int rows = ((msh + rows_batch - 1) / rows_batch) * rows_batch;
+            F2.img_words = rows * F2.strideW;
+        }
+        e->fast_lds_bytes = (F2.img_words + F2.score_words + F2.list_words) * 4;
+        e->cells2.clear();
+        for (const CellDesc &c : e->cells) {
+            const LevelGeom &Lc = G.lv[c.level];
+            FastCell f; memset(&f, 0, sizeof(f));
+            const int a = c.x0 & 3, gxb = c.x0 - a, sw = c.x1 - c.x0, shh = c.y1 - c.y0;
+            f.src_off = Lc.plane_off + (unsigned)((kEdge + c.y0) * Lc.pitch + kPadL + gxb - 4);
+            f.pitch = (unsigned short)Lc.pitch; f.sw = (unsigned char)sw; f.sh = (unsigned char)shh; f.a = (unsigned char)a;
+            f.kpx = (short)(c.offx - 4 - a); f.kpy = (short)(c.offy + 3);
+            const int dwc = sw - 6, c_lo = a + 7, c_hi = c_lo + dwc;
+            const int ngrp = dwc > 0 ? ((c_hi - 1) >> 2) - (c_lo >> 2) + 1 : 1;
+            f.magic = ((1u << 20) + ngrp - 1) / ngrp;
+            e->cells2.push_back(f);
+        }
+        FastParams &FP = e->fast_params;
+        memset(&FP, 0, sizeof(FP));
+        FP.img_words = F2.img_words; FP.score_words = F2.score_words;
+        FP.ini_th = G.ini_th; FP.min_th = G.min_th;
     }
     G.frame_bytes = off;
     G.ncells_total = (int)e->cells.size();
@@ -1573,9 +1423,12 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
     else if (maxn <= 2048) e->octree_maxn = 2048;
     else { set_error("nfeatures too large for the octree kernel (per-level cap %d > 2048)", maxn); return ORBHIP_E_ARG; }
     if (G.ncells_total == 0) { /* tiny image: no FAST cells anywhere; still a valid (empty) result */ }
+    e->fast_params.frame_bytes = G.frame_bytes; e->fast_params.ncells_total = G.ncells_total; e->fast_params.slot_cap = G.slot_cap;
     if (!e->cells.empty()) {
         ORBHIP_HIP_CHECK(hipMalloc(&e->d_cells, e->cells.size() * sizeof(CellDesc)));
         ORBHIP_HIP_CHECK(hipMemcpy(e->d_cells, e->cells.data(), e->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+        ORBHIP_HIP_CHECK(hipMalloc(&e->d_cells2, e->cells2.size() * sizeof(FastCell)));
+        ORBHIP_HIP_CHECK(hipMemcpy(e->d_cells2, e->cells2.data(), e->cells2.size() * sizeof(FastCell), hipMemcpyHostToDevice));
     }
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_tiles, e->tiles.size() * sizeof(TileDesc)));
     ORBHIP_HIP_CHECK(hipMemcpy(e->d_tiles, e->tiles.data(), e->tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
@@ -1629,15 +1482,20 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         }
     }
     if (prof) (void)hipEventRecord(ev[1], s);
-    static const bool fast_v1 = getenv("ORBHIP_FAST_V1") != nullptr;
-    if (G.ncells_total > 0 && (fast_v1 || e->fast_variant == 1))
-        hipLaunchKernelGGL(k_fast_cells, dim3(G.ncells_total, batch), dim3(64), (size_t)e->fast_lds_bytes, s, e->d_pyr, G,
-                           e->d_cells, e->d_cell_cnt, e->d_cell_kp, e->fast_lds);
-    else if (G.ncells_total > 0) {
+    if (G.ncells_total > 0) {
         const dim3 grid(G.ncells_total, batch);
-        const size_t lb = (size_t)e->fast_lds2_bytes;
-#define ORBHIP_FAST2(SWv) hipLaunchKernelGGL(k_fast_cells2<SWv>, grid, dim3(64), lb, s, e->d_pyr, G, e->d_cells, e->d_cell_cnt, e->d_cell_kp, e->fast_lds2)
-        switch (e->fast_lds2.strideW) {
+        const size_t lb = (size_t)e->fast_lds_bytes;
+        FastParams P = e->fast_params;
+        P.dev = e->fast_variant;
+        // remap: frame = lin2 / ncells by multiplication; exact while lin2 * ncells < 2^32
+        P.rcp_cells = (uint32_t)(((1ull << 32) + (unsigned)G.ncells_total - 1) / (unsigned)G.ncells_total);
+        if ((unsigned long long)G.ncells_total * G.ncells_total * (unsigned long long)batch >= (1ull << 32)) {
+            set_error("batch too large for the FAST kernel's work mapping"); return ORBHIP_E_SIZE;
+        }
+#define ORBHIP_FAST2(SWv) hipLaunchKernelGGL(k_fast_cells<SWv>, grid, dim3(64), lb, s, e->d_pyr, e->d_cells2, e->d_cell_cnt, e->d_cell_kp, P)
+        if (e->fast_variant == 2 && e->fast_lds.strideW == 11)   // stamped diagnostic build (tools/fast_ab.py)
+            hipLaunchKernelGGL((k_fast_cells<11, true>), grid, dim3(64), lb, s, e->d_pyr, e->d_cells2, e->d_cell_cnt, e->d_cell_kp, P);
+        else switch (e->fast_lds.strideW) {
         case 11: ORBHIP_FAST2(11); break;
         case 13: ORBHIP_FAST2(13); break;
         case 15: ORBHIP_FAST2(15); break;
@@ -2010,7 +1868,21 @@ int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *
 }
 
 // development switch (not part of include/orbhip.h): 1 = first formulation of the FAST kernel, 0 = current one
-int orbhip_dev_set_fast_variant(orbhip_extractor *e, int v) { if (!e) return ORBHIP_E_ARG; e->fast_variant = v; return ORBHIP_OK; }
+int orbhip_dev_set_fast_variant(orbhip_extractor *e, int v)
+{
+    if (!e) return ORBHIP_E_ARG;
+    e->fast_variant = v;                    // 0 product; 2 stamped diagnostic build; 3 / 4 exit after the prologue / after staging
+    return ORBHIP_OK;
+}
+
+// diagnostic: read (and clear) the per-phase cycle sums of the stamped FAST build (variant 2)
+int orbhip_dev_fast_stamps(unsigned long long out[8])
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(orbhip::g_fast_stamps), sizeof(z)) != hipSuccess) return ORBHIP_E_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(orbhip::g_fast_stamps), z, sizeof(z)) != hipSuccess) return ORBHIP_E_HIP;
+    return ORBHIP_OK;
+}
 
 int orbhip_extractor_set_profiling(orbhip_extractor *e, int on)
 {

@@ -10,11 +10,24 @@ struct TileDesc { short level, tx, ty, pad; };
 constexpr int kBlurTW = 64, kBlurTH = 58;
 // LDS geometry of k_fast_cells, derived on the host from the largest cell of the image size
 struct FastLds {
-    int strideW;      // row stride in dwords (odd): 1 margin dword + staged dwords + 1 spare
-    int div_magic;    // (i * div_magic) >> 20 == i / strideW for i < 8192
-    int scoreW;       // score-map row stride in dwords: (max detection width + 2 halo bytes) rounded up
+    int strideW;      // row stride in dwords (odd) = the kernel's template argument: staged dwords + one real dword on the left
+    int scoreW;       // score-map row stride in dwords (= strideW - 2)
     int img_words, score_words, list_words;
-    int final_in_img; // NMS survivors alias the staged image (dead by then) when slot_cap + 64 <= img_words
+};
+// One FAST cell as k_fast_cells2 wants it: every derived quantity precomputed, one 32-byte scalar load per wavefront
+struct alignas(32) FastCell {
+    uint32_t src_off;        // byte offset inside a frame's pyramid block of LDS (row 0, col 0): row y0, column gxb - 4
+    uint32_t magic;          // ceil(2^20 / ngrp)
+    unsigned short pitch;    // row pitch of the level's padded plane
+    short kpx, kpy;          // keypoint = (LDS col + kpx, detection row + kpy) relative to (minBorderX, minBorderY)
+    unsigned char sw, sh, a; // sub-image size; a = x0 & 3
+    unsigned char pad[15];
+};
+static_assert(sizeof(FastCell) == 32, "FastCell is one s_load_dwordx8");
+struct FastParams {
+    uint32_t frame_bytes, rcp_cells;
+    int ncells_total, slot_cap, ini_th, min_th, img_words, score_words;
+    int dev;   // development switch (timing floors)
 };
 struct DiscTab { unsigned short uv[768]; };  // 749 disc offsets (u | v << 8), zero padded to 12 x 64
 }  // namespace orbhip
@@ -44,10 +57,11 @@ struct orbhip_extractor {
     int octree_maxn = 512;
     orbhip::FastLds fast_lds;   // k_fast_cells dynamic LDS carve-up
     int fast_lds_bytes = 0;
-    orbhip::FastLds fast_lds2;  // k_fast_cells2<SW>: strideW is the template argument
-    int fast_lds2_bytes = 0;
-    int fast_variant = 0;       // development switch: 1 = first formulation
+    int fast_variant = 0;       // development switch (tools/fast_ab.py): 2 stamped build, 3 / 4 timing floors
     orbhip::CellDesc *d_cells = nullptr;
+    std::vector<orbhip::FastCell> cells2;
+    orbhip::FastCell *d_cells2 = nullptr;
+    orbhip::FastParams fast_params;
     orbhip::TileDesc *d_tiles = nullptr;
     short *d_tabs = nullptr;
     orbhip::DiscTab *d_disc = nullptr;

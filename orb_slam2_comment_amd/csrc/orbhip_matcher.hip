@@ -35,16 +35,19 @@ struct DevFrame {
 // Batched (device-resident) calls: pair p = blockIdx.y uses element strides cap / qcap; the single-pair
 // host path passes zero strides and null count pointers.
 struct Batch {
-    const int *n_dev;    // per-pair train keypoint counts, or null (use F.n)
+    const int *n_dev;    // per-frame train keypoint counts, or null (use F.n)
     const int *nq_dev;   // per-pair query counts, or null (use the nq argument)
     int cap, qcap;
+    int t0 = 0, ts = 1;    // train side of pair p = frame t0 + p*ts of the extractor-layout arrays
+    int qd0 = 0, qds = 1;  // query descriptors of pair p = frame qd0 + p*qds of their array
 };
 __device__ __forceinline__ void batch_frame(DevFrame &F, const Batch &B, int pair)
 {
-    F.keys += (size_t)pair * B.cap;
-    F.desc += (size_t)pair * B.cap * 32;
-    if (F.u_right) F.u_right += (size_t)pair * B.cap;
-    if (B.n_dev) F.n = min(B.n_dev[pair], B.cap);
+    const size_t f = (size_t)(B.t0 + pair * B.ts);
+    F.keys += f * B.cap;
+    F.desc += f * B.cap * 32;
+    if (F.u_right) F.u_right += f * B.cap;
+    if (B.n_dev) F.n = min(B.n_dev[f], B.cap);
 }
 
 __device__ __forceinline__ int hamming256(const uint32_t *a, const uint32_t *b)
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const uint32_
     batch_frame(F, B, pair);
     ord += (size_t)pair * B.cap;
     q += (size_t)pair * B.qcap;
-    qdesc += (size_t)pair * B.qcap * 32;
+    qdesc += (size_t)(B.qd0 + pair * B.qds) * B.qcap * 32;
     cand += (size_t)pair * B.qcap * stride;
     cnt += (size_t)pair * B.qcap;
     if (B.nq_dev) nq = min(B.nq_dev[pair], B.qcap);
@@ -668,11 +671,23 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
                                                 const unsigned long long *__restrict__ cand,
                                                 const int *__restrict__ cnt, int stride,
                                                 const uint8_t *__restrict__ taken_in, float nnratio,
-                                                int check_ori, int *__restrict__ out, int *__restrict__ out_n)
+                                                int check_ori, int *__restrict__ out, int *__restrict__ out_n, Batch B)
 {
     extern __shared__ unsigned char resolve_lds[];
     ResolveShared &S = *reinterpret_cast<ResolveShared *>(resolve_lds);
     const int lane = threadIdx.x;
+    if (B.qcap > 0) {   // batched (device-resident) call: one wavefront per pair
+        const int pair = blockIdx.x;
+        batch_frame(F, B, pair);
+        if (qkeys) qkeys += (size_t)(B.qd0 + pair * B.qds) * B.qcap;
+        q += (size_t)pair * B.qcap;
+        cand += (size_t)pair * B.qcap * stride;
+        cnt += (size_t)pair * B.qcap;
+        if (taken_in) taken_in += (size_t)pair * B.cap;
+        out += (size_t)pair * (mode == 2 ? B.qcap : B.cap);
+        out_n += pair;
+        if (B.nq_dev) nq = min(B.nq_dev[pair], B.qcap);
+    }
     const int n = F.n;
     for (int i = lane; i < n; i += 64) {
         S.block[i] = (mode == 2) ? 0xffff : (unsigned short)(taken_in ? taken_in[i] != 0 : 0);
@@ -1123,6 +1138,211 @@ __global__ void k_stereo_from_rgbd(const orbhip_keypoint *__restrict__ keys, con
 }
 
 // ---- Frame::ComputeStereoMatches (Frame.cc:466-640) -----------------------------------------
+// ---------------------------------------------------------------------------
+// Projection prologues (include/orbhip.h "projection prologues on the device"): one thread per map point.  Every
+// float operation that feeds a comparison is written out un-contracted, in the order DESIGN.md section 3 states.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dot3_row(const float *r, float x, float y, float z, float t)
+{
+    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r[0], x), __fmul_rn(r[1], y)), __fmul_rn(r[2], z)), t);
+}
+
+// fdlibm log in IEEE double, separate operations, one rounding to float (the deterministic logf of DESIGN.md section 3)
+__device__ __forceinline__ float det_logf(float xf)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (!(xf > 0.0f)) return xf == 0.0f ? -INFINITY : NAN;
+    if (isinf(xf)) return xf;
+    double x = (double)xf;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    int hx = (int)(bits >> 32);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i = (hx + 0x95f64) & 0x100000;
+    bits = ((unsigned long long)(unsigned)(hx | (i ^ 0x3ff00000)) << 32) | (bits & 0xffffffffull);
+    x = __longlong_as_double((long long)bits);
+    k += i >> 20;
+    const double f = __dsub_rn(x, 1.0);
+    const double s = __ddiv_rn(f, __dadd_rn(2.0, f));
+    const double dk = (double)k;
+    const double z = __dmul_rn(s, s);
+    const double w = __dmul_rn(z, z);
+    const double t1 = __dmul_rn(w, __dadd_rn(Lg2, __dmul_rn(w, __dadd_rn(Lg4, __dmul_rn(w, Lg6)))));
+    const double t2 = __dmul_rn(z, __dadd_rn(Lg1, __dmul_rn(w, __dadd_rn(Lg3, __dmul_rn(w, __dadd_rn(Lg5, __dmul_rn(w, Lg7)))))));
+    const double R = __dadd_rn(t2, t1);
+    const double hfsq = __dmul_rn(__dmul_rn(0.5, f), f);
+    const double r = __dsub_rn(__dmul_rn(dk, ln2_hi),
+                               __dsub_rn(__dsub_rn(hfsq, __dadd_rn(__dmul_rn(s, __dadd_rn(hfsq, R)), __dmul_rn(dk, ln2_lo))), f));
+    return (float)r;
+}
+
+struct ProjBatch {
+    const float *Tcw, *Tlw;            // [pairs][12]
+    const orbhip_keypoint *keys;       // [frames][cap]
+    const int *n_dev;                  // [frames] or null (use n)
+    const float *world;                // [frames][cap][3]
+    const uint8_t *flags;              // [frames][cap]
+    orbhip_query *q;                   // [pairs][cap]
+    int *nq;                           // [pairs] or null
+    int n, cap, l0, ls;
+};
+
+// src/ORBmatcher.cc:1339-1390
+__global__ __launch_bounds__(256) void k_project_last_frame(ProjBatch B, orbhip_camera cam, float th, int mono)
+{
+    const int pair = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const size_t fl = (size_t)(B.l0 + pair * B.ls);
+    const int n = B.n_dev ? min(B.n_dev[fl], B.cap) : B.n;
+    if (i == 0 && B.nq) B.nq[pair] = n;
+    if (i >= n) return;
+    const float *Tcw = B.Tcw + (size_t)pair * 12, *Tlw = B.Tlw + (size_t)pair * 12;
+    orbhip_query Q;
+    Q.valid = 0; Q.u = 0; Q.v = 0; Q.radius = 0; Q.min_level = 0; Q.max_level = 0; Q.ur = 0; Q.level_aux = 0; Q.angle = 0; Q.observed = 0;
+    orbhip_query *dst = B.q + (size_t)pair * B.cap + i;
+    const unsigned fg = B.flags[fl * B.cap + i];
+    if (fg & ORBHIP_POINT_PRESENT) {
+        // twc = -Rcw.t()*tcw; tlc = Rlw*twc+tlw (:1342-1347); a dozen flops, recomputed per thread
+        float twc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            twc[c] = -__fadd_rn(__fadd_rn(__fmul_rn(Tcw[c], Tcw[3]), __fmul_rn(Tcw[4 + c], Tcw[7])), __fmul_rn(Tcw[8 + c], Tcw[11]));
+        const float tlc_z = dot3_row(Tlw + 8, twc[0], twc[1], twc[2], Tlw[11]);
+        const bool forward = tlc_z > cam.mb && !mono, backward = -tlc_z > cam.mb && !mono;
+        const float *X = B.world + (fl * B.cap + i) * 3;
+        const float x = X[0], y = X[1], z = X[2];
+        const float xc = dot3_row(Tcw, x, y, z, Tcw[3]);
+        const float yc = dot3_row(Tcw + 4, x, y, z, Tcw[7]);
+        const float zc = dot3_row(Tcw + 8, x, y, z, Tcw[11]);
+        const float invzc = (float)__ddiv_rn(1.0, (double)zc);
+        if (!(invzc < 0)) {
+            const float u = __fadd_rn(__fmul_rn(__fmul_rn(cam.fx, xc), invzc), cam.cx);
+            const float v = __fadd_rn(__fmul_rn(__fmul_rn(cam.fy, yc), invzc), cam.cy);
+            if (!(u < cam.min_x || u > cam.max_x) && !(v < cam.min_y || v > cam.max_y)) {
+                const orbhip_keypoint kp = B.keys[fl * B.cap + i];
+                const int o = kp.octave;
+                Q.valid = 1; Q.u = u; Q.v = v;
+                Q.radius = __fmul_rn(th, cam.scale_factors[min(max(o, 0), ORBHIP_MAX_LEVELS - 1)]);
+                if (forward) { Q.min_level = o; Q.max_level = -1; }
+                else if (backward) { Q.min_level = 0; Q.max_level = o; }
+                else { Q.min_level = o - 1; Q.max_level = o + 1; }
+                Q.ur = __fsub_rn(u, __fmul_rn(cam.mbf, invzc));
+                Q.level_aux = o;
+                Q.angle = kp.angle;
+                Q.observed = (fg & ORBHIP_POINT_OBSERVED) ? 1 : 0;
+            }
+        }
+    }
+    *dst = Q;
+}
+
+struct FrustumBatch {
+    const float *Tcw;                       // [frames][12]
+    const int *np_dev;                      // [frames] or null (use n)
+    const float *world, *normal;            // [frames][pcap][3]
+    const float *max_dist, *min_dist;       // [frames][pcap]
+    const uint8_t *flags;                   // [frames][pcap]
+    orbhip_query *q;                        // [frames][pcap]
+    float *view_cos;                        // [frames][pcap] or null
+    int n, pcap;
+};
+
+// src/Frame.cc:269-325, src/MapPoint.cc:400-418, src/ORBmatcher.cc:52-69, :131-137
+__global__ __launch_bounds__(256) void k_frustum_queries(FrustumBatch B, orbhip_camera cam, float cos_limit, float th)
+{
+    const int fr = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n = B.np_dev ? min(B.np_dev[fr], B.pcap) : B.n;
+    if (i >= n) return;
+    const size_t e = (size_t)fr * B.pcap + i;
+    const float *Tcw = B.Tcw + (size_t)fr * 12;
+    orbhip_query Q;
+    Q.valid = 0; Q.u = 0; Q.v = 0; Q.radius = 0; Q.min_level = 0; Q.max_level = 0; Q.ur = 0; Q.level_aux = 0; Q.angle = 0; Q.observed = 0;
+    float vc = 0.0f;
+    const unsigned fg = B.flags[e];
+    do {
+        if (!(fg & ORBHIP_POINT_PRESENT)) break;
+        float Ow[3];   // mOw = -mRcw.t()*mtcw
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            Ow[c] = -__fadd_rn(__fadd_rn(__fmul_rn(Tcw[c], Tcw[3]), __fmul_rn(Tcw[4 + c], Tcw[7])), __fmul_rn(Tcw[8 + c], Tcw[11]));
+        const float *P = B.world + e * 3;
+        const float px = P[0], py = P[1], pz = P[2];
+        const float PcX = dot3_row(Tcw, px, py, pz, Tcw[3]);
+        const float PcY = dot3_row(Tcw + 4, px, py, pz, Tcw[7]);
+        const float PcZ = dot3_row(Tcw + 8, px, py, pz, Tcw[11]);
+        if (PcZ < 0.0f) break;
+        const float invz = __fdiv_rn(1.0f, PcZ);
+        const float u = __fadd_rn(__fmul_rn(__fmul_rn(cam.fx, PcX), invz), cam.cx);
+        const float v = __fadd_rn(__fmul_rn(__fmul_rn(cam.fy, PcY), invz), cam.cy);
+        if (u < cam.min_x || u > cam.max_x) break;
+        if (v < cam.min_y || v > cam.max_y) break;
+        const float md = B.max_dist[e];
+        const float maxDistance = __fmul_rn(1.2f, md), minDistance = __fmul_rn(0.8f, B.min_dist[e]);
+        const float ox = __fsub_rn(px, Ow[0]), oy = __fsub_rn(py, Ow[1]), oz = __fsub_rn(pz, Ow[2]);
+        const double ss = __dadd_rn(__dadd_rn(__dmul_rn((double)ox, (double)ox), __dmul_rn((double)oy, (double)oy)), __dmul_rn((double)oz, (double)oz));
+        const float dist = (float)__dsqrt_rn(ss);
+        if (dist < minDistance || dist > maxDistance) break;
+        const float *Pn = B.normal + e * 3;
+        const double dot = __dadd_rn(__dadd_rn(__dmul_rn((double)ox, (double)Pn[0]), __dmul_rn((double)oy, (double)Pn[1])), __dmul_rn((double)oz, (double)Pn[2]));
+        const float viewCos = (float)__ddiv_rn(dot, (double)dist);
+        if (viewCos < cos_limit) break;
+        const float ratio = __fdiv_rn(md, dist);
+        const float fl = ceilf(__fdiv_rn(det_logf(ratio), cam.log_scale_factor));
+        int nScale = fl >= (float)cam.n_levels ? cam.n_levels - 1 : (fl < 0 ? 0 : (int)fl);
+        if (!(fl == fl)) nScale = 0;
+        float r = (double)viewCos > 0.998 ? 2.5f : 4.0f;
+        if (th != 1.0f) r = __fmul_rn(r, th);
+        Q.valid = 1; Q.u = u; Q.v = v;
+        Q.radius = __fmul_rn(r, cam.scale_factors[min(max(nScale, 0), ORBHIP_MAX_LEVELS - 1)]);
+        Q.min_level = nScale - 1; Q.max_level = nScale;
+        Q.ur = __fsub_rn(u, __fmul_rn(cam.mbf, invz));
+        Q.level_aux = nScale;
+        Q.observed = (fg & ORBHIP_POINT_OBSERVED) ? 1 : 0;
+        vc = viewCos;
+    } while (0);
+    B.q[e] = Q;
+    if (B.view_cos) B.view_cos[e] = vc;
+}
+
+// SearchForInitialization, device-resident form: queries = level-0 keypoints of F1 searched around vbPrevMatched
+// (src/ORBmatcher.cc:418-425); `reset` first sets vbPrevMatched[i] = F1.mvKeysUn[i].pt (src/Tracking.cc:578-580).
+__global__ __launch_bounds__(256) void k_init_queries(const orbhip_keypoint *__restrict__ keys, const int *__restrict__ n_dev,
+                                                      int cap, int f0, int fs, float *__restrict__ prev, int reset,
+                                                      float window, orbhip_query *__restrict__ q, int *__restrict__ nq)
+{
+    const int pair = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const size_t f1 = (size_t)(f0 + pair * fs);
+    const int n = min(n_dev[f1], cap);
+    if (i == 0) nq[pair] = n;
+    if (i >= n) return;
+    const orbhip_keypoint kp = keys[f1 * cap + i];
+    float *pm = prev + ((size_t)pair * cap + i) * 2;
+    if (reset) { pm[0] = kp.x; pm[1] = kp.y; }
+    orbhip_query Q;
+    Q.valid = kp.octave > 0 ? 0 : 1;
+    Q.u = pm[0]; Q.v = pm[1];
+    Q.radius = window;
+    Q.min_level = kp.octave; Q.max_level = kp.octave;
+    Q.ur = 0; Q.level_aux = 0; Q.angle = kp.angle; Q.observed = 0;
+    q[(size_t)pair * cap + i] = Q;
+}
+
+// vbPrevMatched[i1] = F2.mvKeysUn[vnMatches12[i1]].pt for every match (src/ORBmatcher.cc:515-517)
+__global__ __launch_bounds__(256) void k_init_update_prev(const orbhip_keypoint *__restrict__ keys, int cap, int f0, int fs,
+                                                          const int *__restrict__ nq, const int *__restrict__ m12,
+                                                          float *__restrict__ prev)
+{
+    const int pair = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq[pair]) return;
+    const int j = m12[(size_t)pair * cap + i];
+    if (j < 0) return;
+    const orbhip_keypoint kp = keys[(size_t)(f0 + pair * fs) * cap + j];
+    float *pm = prev + ((size_t)pair * cap + i) * 2;
+    pm[0] = kp.x; pm[1] = kp.y;
+}
+
 struct StereoGeom {
     int nlevels, nrows;
     const uint8_t *left[ORBHIP_MAX_LEVELS], *right[ORBHIP_MAX_LEVELS];
@@ -1481,7 +1701,7 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
     if ((rc = ensure_resolve_attr(m))) return rc;
     if (mode == 2)   // SearchForInitialization: match stealing depends on the running minimum distance -> serial replay
         hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(ResolveShared), m->stream, mode, D, d_qkeys, d_q, nq, d_cand,
-                           d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout);
+                           d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout, one);
     else
         hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), sizeof(ResolveParShared), m->stream, mode, D, d_q, nq, d_cand,
                            d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout, one, th_accept, all_block);
@@ -2090,7 +2310,7 @@ int orbhip_search_by_projection_points(orbhip_matcher *m, const orbhip_frame_vie
 static int search_device(orbhip_matcher *m, int mode, int pairs, const void *d_kps, const void *d_desc, const void *d_n,
                          int cap, const void *d_u_right, const void *d_taken, float min_x, float min_y, float grid_inv_w,
                          float grid_inv_h, const void *d_q, const void *d_qdesc, const void *d_nq, int qcap, float nnratio,
-                         int check_ori, void *d_assign, void *d_nmatches)
+                         int check_ori, void *d_assign, void *d_nmatches, int t0 = 0, int ts = 1, int qd0 = 0, int qds = 1)
 {
     if (!m || pairs <= 0 || !d_kps || !d_desc || !d_n || !d_q || !d_qdesc || !d_nq || !d_assign || !d_nmatches || cap <= 0 || qcap <= 0)
         return ORBHIP_E_ARG;
@@ -2112,7 +2332,7 @@ static int search_device(orbhip_matcher *m, int mode, int pairs, const void *d_k
     DevFrame D;
     D.n = cap; D.keys = (const orbhip_keypoint *)d_kps; D.desc = (const uint8_t *)d_desc; D.u_right = (const float *)d_u_right;
     D.min_x = min_x; D.min_y = min_y; D.inv_w = grid_inv_w; D.inv_h = grid_inv_h;
-    const Batch B = {(const int *)d_n, (const int *)d_nq, cap, qcap};
+    const Batch B = {(const int *)d_n, (const int *)d_nq, cap, qcap, t0, ts, qd0, qds};
     hipLaunchKernelGGL(k_grid_order, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, D, d_ord, B);
     hipLaunchKernelGGL(k_window_search, dim3((qcap + 3) / 4, pairs), dim3(256), 0, m->stream, D, d_ord, (const orbhip_query *)d_q,
                        (const uint8_t *)d_qdesc, qcap, d_cand, d_cnt, stride, 1, B);
@@ -2184,6 +2404,160 @@ int orbhip_compute_stereo_matches_device(orbhip_matcher *m, orbhip_extractor *le
     hipLaunchKernelGGL(k_stereo_cull, dim3(pairs), dim3(256), 0, m->stream, cap, d_sad, (float *)d_u_right, (float *)d_depth,
                        (int *)d_nmatches, B);
     ORBHIP_HIP_CHECK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_search_for_initialization_device(orbhip_matcher *m, int pairs, const void *d_kps, const void *d_desc,
+                                            const void *d_n, int cap, int f1_first, int f1_step, int f2_first,
+                                            int f2_step, float min_x, float min_y, float grid_inv_w, float grid_inv_h,
+                                            int reset_prev, void *d_prev_matched, int window_size, float nnratio,
+                                            int check_ori, void *d_matches12, void *d_nmatches)
+{
+    if (!m || pairs <= 0 || cap <= 0 || !d_kps || !d_desc || !d_n || !d_prev_matched || !d_matches12 || !d_nmatches)
+        return ORBHIP_E_ARG;
+    if (cap > kResolveMax) {
+        set_error("matcher: cap %d exceeds the LDS-resident limit %d", cap, kResolveMax);
+        return ORBHIP_E_CAPACITY;
+    }
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    int rc;
+    void *p;
+    if ((rc = scratch(m, S_ORD, (size_t)pairs * cap * sizeof(uint32_t), &p))) return rc;
+    uint32_t *d_ord = (uint32_t *)p;
+    const int stride = (cap + 1) & ~1;
+    if ((rc = scratch(m, S_CAND, (size_t)pairs * cap * stride * sizeof(unsigned long long), &p))) return rc;
+    unsigned long long *d_cand = (unsigned long long *)p;
+    if ((rc = scratch(m, S_CNT, (size_t)pairs * cap * sizeof(int), &p))) return rc;
+    int *d_cnt = (int *)p;
+    if ((rc = scratch(m, S_Q, (size_t)pairs * cap * sizeof(orbhip_query), &p))) return rc;
+    orbhip_query *d_q = (orbhip_query *)p;
+    if ((rc = scratch(m, S_TAKEN, (size_t)pairs * sizeof(int), &p))) return rc;
+    int *d_nq = (int *)p;
+    if ((rc = ensure_resolve_attr(m))) return rc;
+    const orbhip_keypoint *keys = (const orbhip_keypoint *)d_kps;
+    hipLaunchKernelGGL(k_init_queries, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, keys, (const int *)d_n, cap,
+                       f1_first, f1_step, (float *)d_prev_matched, reset_prev, (float)window_size, d_q, d_nq);
+    DevFrame D;
+    D.n = cap; D.keys = keys; D.desc = (const uint8_t *)d_desc; D.u_right = nullptr;
+    D.min_x = min_x; D.min_y = min_y; D.inv_w = grid_inv_w; D.inv_h = grid_inv_h;
+    const Batch B = {(const int *)d_n, d_nq, cap, cap, f2_first, f2_step, f1_first, f1_step};
+    hipLaunchKernelGGL(k_grid_order, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, D, d_ord, B);
+    hipLaunchKernelGGL(k_window_search, dim3((cap + 3) / 4, pairs), dim3(256), 0, m->stream, D, d_ord, d_q,
+                       (const uint8_t *)d_desc, cap, d_cand, d_cnt, stride, 0, B);
+    hipLaunchKernelGGL(k_resolve, dim3(pairs), dim3(64), sizeof(ResolveShared), m->stream, 2, D, keys, d_q, cap, d_cand, d_cnt,
+                       stride, (const uint8_t *)nullptr, nnratio, check_ori, (int *)d_matches12, (int *)d_nmatches, B);
+    hipLaunchKernelGGL(k_init_update_prev, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, keys, cap, f2_first, f2_step,
+                       d_nq, (const int *)d_matches12, (float *)d_prev_matched);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_project_last_frame_device(orbhip_matcher *m, int pairs, const orbhip_camera *cam, const void *d_Tcw,
+                                     const void *d_Tlw, const void *d_kps, const void *d_n, int cap, int last_first,
+                                     int last_step, const void *d_world, const void *d_flags, float th, int mono,
+                                     void *d_q, void *d_nq)
+{
+    if (!m || !cam || pairs <= 0 || cap <= 0 || !d_Tcw || !d_Tlw || !d_kps || !d_n || !d_world || !d_flags || !d_q ||
+        cam->n_levels < 1 || cam->n_levels > ORBHIP_MAX_LEVELS)
+        return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    ProjBatch B = {(const float *)d_Tcw, (const float *)d_Tlw, (const orbhip_keypoint *)d_kps, (const int *)d_n,
+                   (const float *)d_world, (const uint8_t *)d_flags, (orbhip_query *)d_q, (int *)d_nq, 0, cap, last_first, last_step};
+    hipLaunchKernelGGL(k_project_last_frame, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, B, *cam, th, mono);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_track_last_frame_device(orbhip_matcher *m, int pairs, const orbhip_camera *cam, const void *d_Tcw,
+                                   const void *d_Tlw, const void *d_kps, const void *d_desc, const void *d_n, int cap,
+                                   int cur_first, int cur_step, int last_first, int last_step, const void *d_world,
+                                   const void *d_flags, const void *d_u_right, const void *d_taken, float th, int mono,
+                                   int check_ori, void *d_assign, void *d_nmatches)
+{
+    if (!m || !cam || pairs <= 0 || cap <= 0 || !d_desc) return ORBHIP_E_ARG;
+    int rc;
+    void *p;
+    if ((rc = scratch(m, S_Q, (size_t)pairs * cap * sizeof(orbhip_query), &p))) return rc;
+    orbhip_query *d_q = (orbhip_query *)p;
+    if ((rc = scratch(m, S_TAKEN, (size_t)pairs * sizeof(int), &p))) return rc;   // per-pair query counts
+    int *d_nq = (int *)p;
+    if ((rc = orbhip_project_last_frame_device(m, pairs, cam, d_Tcw, d_Tlw, d_kps, d_n, cap, last_first, last_step, d_world,
+                                               d_flags, th, mono, d_q, d_nq)))
+        return rc;
+    // Frame::ComputeImageBounds / mfGridElement{Width,Height}Inv (src/Frame.cc:99-100) from the camera's bounds
+    const float inv_w = (float)GRID_COLS / (cam->max_x - cam->min_x), inv_h = (float)GRID_ROWS / (cam->max_y - cam->min_y);
+    return search_device(m, 0, pairs, d_kps, d_desc, d_n, cap, d_u_right, d_taken, cam->min_x, cam->min_y, inv_w, inv_h, d_q,
+                         d_desc, d_nq, cap, 0.f, check_ori, d_assign, d_nmatches, cur_first, cur_step, last_first, last_step);
+}
+
+int orbhip_frustum_queries_device(orbhip_matcher *m, int frames, const orbhip_camera *cam, const void *d_Tcw, int pcap,
+                                  const void *d_np, const void *d_world, const void *d_normal, const void *d_max_dist,
+                                  const void *d_min_dist, const void *d_flags, float viewing_cos_limit, float th,
+                                  void *d_q, void *d_view_cos)
+{
+    if (!m || !cam || frames <= 0 || pcap <= 0 || !d_Tcw || !d_np || !d_world || !d_normal || !d_max_dist || !d_min_dist ||
+        !d_flags || !d_q || cam->n_levels < 1 || cam->n_levels > ORBHIP_MAX_LEVELS)
+        return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    FrustumBatch B = {(const float *)d_Tcw, (const int *)d_np, (const float *)d_world, (const float *)d_normal,
+                      (const float *)d_max_dist, (const float *)d_min_dist, (const uint8_t *)d_flags, (orbhip_query *)d_q,
+                      (float *)d_view_cos, 0, pcap};
+    hipLaunchKernelGGL(k_frustum_queries, dim3((pcap + 255) / 256, frames), dim3(256), 0, m->stream, B, *cam, viewing_cos_limit, th);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_project_last_frame(orbhip_matcher *m, const orbhip_camera *cam, const float *Tcw, const float *Tlw, int n,
+                              const float *world, const uint8_t *flags, const orbhip_keypoint *last_keys, float th,
+                              int mono, orbhip_query *q)
+{
+    if (!m || !cam || n < 0 || !Tcw || !Tlw || !q || cam->n_levels < 1 || cam->n_levels > ORBHIP_MAX_LEVELS) return ORBHIP_E_ARG;
+    if (n == 0) return ORBHIP_OK;
+    if (!world || !flags || !last_keys) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    Stage st;
+    int rc = stage_begin(m, 2 * al256(48) + al256((size_t)n * 12) + al256((size_t)n) + al256((size_t)n * sizeof(orbhip_keypoint)), &st);
+    if (rc) return rc;
+    const float *dT = (const float *)st.put(Tcw, 48), *dL = (const float *)st.put(Tlw, 48);
+    const float *dW = (const float *)st.put(world, (size_t)n * 12);
+    const uint8_t *dF = (const uint8_t *)st.put(flags, (size_t)n);
+    const orbhip_keypoint *dK = (const orbhip_keypoint *)st.put(last_keys, (size_t)n * sizeof(orbhip_keypoint));
+    if ((rc = stage_commit(m, &st))) return rc;
+    void *p;
+    if ((rc = scratch(m, S_Q, (size_t)n * sizeof(orbhip_query), &p))) return rc;
+    ProjBatch B = {dT, dL, dK, nullptr, dW, dF, (orbhip_query *)p, nullptr, n, n, 0, 0};
+    hipLaunchKernelGGL(k_project_last_frame, dim3((n + 255) / 256, 1), dim3(256), 0, m->stream, B, *cam, th, mono);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(q, p, (size_t)n * sizeof(orbhip_query), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBHIP_OK;
+}
+
+int orbhip_frustum_queries(orbhip_matcher *m, const orbhip_camera *cam, const float *Tcw, int n, const float *world,
+                           const float *normal, const float *max_dist, const float *min_dist, const uint8_t *flags,
+                           float viewing_cos_limit, float th, orbhip_query *q, float *view_cos)
+{
+    if (!m || !cam || n < 0 || !Tcw || !q || cam->n_levels < 1 || cam->n_levels > ORBHIP_MAX_LEVELS) return ORBHIP_E_ARG;
+    if (n == 0) return ORBHIP_OK;
+    if (!world || !normal || !max_dist || !min_dist || !flags) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    Stage st;
+    int rc = stage_begin(m, al256(48) + 2 * al256((size_t)n * 12) + 2 * al256((size_t)n * 4) + al256((size_t)n), &st);
+    if (rc) return rc;
+    const float *dT = (const float *)st.put(Tcw, 48);
+    const float *dW = (const float *)st.put(world, (size_t)n * 12), *dN = (const float *)st.put(normal, (size_t)n * 12);
+    const float *dMx = (const float *)st.put(max_dist, (size_t)n * 4), *dMn = (const float *)st.put(min_dist, (size_t)n * 4);
+    const uint8_t *dF = (const uint8_t *)st.put(flags, (size_t)n);
+    if ((rc = stage_commit(m, &st))) return rc;
+    void *p, *pv;
+    if ((rc = scratch(m, S_Q, (size_t)n * sizeof(orbhip_query), &p))) return rc;
+    if ((rc = scratch(m, S_OUT, (size_t)n * sizeof(float), &pv))) return rc;
+    FrustumBatch B = {dT, nullptr, dW, dN, dMx, dMn, dF, (orbhip_query *)p, (float *)pv, n, n};
+    hipLaunchKernelGGL(k_frustum_queries, dim3((n + 255) / 256, 1), dim3(256), 0, m->stream, B, *cam, viewing_cos_limit, th);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(q, p, (size_t)n * sizeof(orbhip_query), hipMemcpyDeviceToHost, m->stream));
+    if (view_cos) ORBHIP_HIP_CHECK(hipMemcpyAsync(view_cos, pv, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
     return ORBHIP_OK;
 }
 

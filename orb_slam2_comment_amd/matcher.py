@@ -268,6 +268,69 @@ class ORBmatcher:
             self._h, pairs, d_kps, d_desc, d_n, cap, d_u_right, d_taken, b[0], b[1], inv_w, inv_h, d_q, d_qdesc, d_nq,
             qcap, int(self.mbCheckOrientation), d_assign, d_nmatches), "orbhip_search_by_projection_frame_device")
 
+    def SearchForInitializationDevice(self, pairs, d_kps, d_desc, d_n, cap, f1_first, f1_step, f2_first, f2_step, bounds,
+                                      keep_prev, d_prev_matched, windowSize, d_matches12, d_nmatches):
+        """Batched, device-resident SearchForInitialization; keep_prev = 0 resets vbPrevMatched to F1's keypoints."""
+        b = [np.float32(v) for v in bounds]
+        inv_w = np.float32(FRAME_GRID_COLS) / (b[2] - b[0])
+        inv_h = np.float32(FRAME_GRID_ROWS) / (b[3] - b[1])
+        check(self._lib.orbhip_search_for_initialization_device(
+            self._h, pairs, d_kps, d_desc, d_n, cap, f1_first, f1_step, f2_first, f2_step, b[0], b[1], inv_w, inv_h,
+            int(not keep_prev), d_prev_matched, int(windowSize), self.mfNNratio, int(self.mbCheckOrientation), d_matches12,
+            d_nmatches), "orbhip_search_for_initialization_device")
+
+    # -- projection prologues on the device (src/ORBmatcher.cc:1339-1390; src/Frame.cc:269-325) ------------------
+    def ProjectLastFrame(self, cam, Tcw, Tlw, world, flags, last_keys, th, bMono):
+        """Prologue of SearchByProjection(CurrentFrame, LastFrame, th, bMono): QUERY_DTYPE[n] for
+        SearchByProjectionFrame.  Tcw / Tlw: 4x4 or 3x4 float32; world [n,3]; flags [n] uint8 (POINT_* bits)."""
+        Tc = np.ascontiguousarray(np.asarray(Tcw, np.float32)[:3, :4])
+        Tl = np.ascontiguousarray(np.asarray(Tlw, np.float32)[:3, :4])
+        world = np.ascontiguousarray(world, np.float32).reshape(-1, 3)
+        flags = np.ascontiguousarray(flags, np.uint8)
+        keys = np.ascontiguousarray(last_keys, KP_DTYPE)
+        n = len(keys)
+        q = np.zeros(n, QUERY_DTYPE)
+        check(self._lib.orbhip_project_last_frame(self._h, C.byref(cam), ptr(Tc), ptr(Tl), n, ptr(world), ptr(flags),
+                                                  ptr(keys), float(th), int(bMono), ptr(q)), "orbhip_project_last_frame")
+        return q
+
+    def FrustumQueries(self, cam, Tcw, world, normal, max_dist, min_dist, flags, viewingCosLimit, th):
+        """Frame::isInFrustum for n map points + the window of SearchByProjection(F, vpMapPoints, th).
+        Returns (QUERY_DTYPE[n], view_cos[n])."""
+        Tc = np.ascontiguousarray(np.asarray(Tcw, np.float32)[:3, :4])
+        world = np.ascontiguousarray(world, np.float32).reshape(-1, 3)
+        normal = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        mx, mn = np.ascontiguousarray(max_dist, np.float32), np.ascontiguousarray(min_dist, np.float32)
+        flags = np.ascontiguousarray(flags, np.uint8)
+        n = len(world)
+        q, vc = np.zeros(n, QUERY_DTYPE), np.zeros(n, np.float32)
+        check(self._lib.orbhip_frustum_queries(self._h, C.byref(cam), ptr(Tc), n, ptr(world), ptr(normal), ptr(mx), ptr(mn),
+                                               ptr(flags), float(viewingCosLimit), float(th), ptr(q), ptr(vc)),
+              "orbhip_frustum_queries")
+        return q, vc
+
+    def ProjectLastFrameDevice(self, pairs, cam, d_Tcw, d_Tlw, d_kps, d_n, cap, last_first, last_step, d_world, d_flags, th,
+                               bMono, d_q, d_nq):
+        check(self._lib.orbhip_project_last_frame_device(self._h, pairs, C.byref(cam), d_Tcw, d_Tlw, d_kps, d_n, cap,
+                                                         last_first, last_step, d_world, d_flags, float(th), int(bMono),
+                                                         d_q, d_nq), "orbhip_project_last_frame_device")
+
+    def TrackLastFrameDevice(self, pairs, cam, d_Tcw, d_Tlw, d_kps, d_desc, d_n, cap, cur_first, cur_step, last_first,
+                             last_step, d_world, d_flags, th, bMono, d_assign, d_nmatches, d_u_right=0, d_taken=0):
+        """Prologue + search + resolve + rotation cull of SearchByProjection(CurrentFrame, LastFrame, th, bMono) for
+        `pairs` (current, last) frame pairs of the extractor output arrays, all on the device, one stream."""
+        check(self._lib.orbhip_track_last_frame_device(self._h, pairs, C.byref(cam), d_Tcw, d_Tlw, d_kps, d_desc, d_n, cap,
+                                                       cur_first, cur_step, last_first, last_step, d_world, d_flags,
+                                                       d_u_right, d_taken, float(th), int(bMono),
+                                                       int(self.mbCheckOrientation), d_assign, d_nmatches),
+              "orbhip_track_last_frame_device")
+
+    def FrustumQueriesDevice(self, frames, cam, d_Tcw, pcap, d_np, d_world, d_normal, d_max_dist, d_min_dist, d_flags,
+                             viewingCosLimit, th, d_q, d_view_cos=0):
+        check(self._lib.orbhip_frustum_queries_device(self._h, frames, C.byref(cam), d_Tcw, pcap, d_np, d_world, d_normal,
+                                                      d_max_dist, d_min_dist, d_flags, float(viewingCosLimit), float(th),
+                                                      d_q, d_view_cos), "orbhip_frustum_queries_device")
+
     def SearchByProjectionPointsDevice(self, pairs, d_kps, d_desc, d_n, cap, bounds, d_q, d_qdesc, d_nq, qcap, d_assign,
                                        d_nmatches, d_u_right=0, d_taken=0):
         b = [np.float32(v) for v in bounds]
@@ -307,6 +370,20 @@ class ORBmatcher:
 def RadiusByViewingCos(viewCos):
     """src/ORBmatcher.cc:131-137"""
     return 2.5 if viewCos > 0.998 else 4.0
+
+
+def make_camera(fx, fy, cx, cy, bounds, scale_factors, mbf=0.0, mb=0.0):
+    """orbhip_camera from plain numbers.  bounds = (mnMinX, mnMinY, mnMaxX, mnMaxY); mfLogScaleFactor =
+    log(mfScaleFactor) as the Frame constructor computes it (src/Frame.cc:71: float log of the float scale factor)."""
+    cam = capi.Camera()
+    cam.fx, cam.fy, cam.cx, cam.cy, cam.mbf, cam.mb = fx, fy, cx, cy, mbf, mb
+    cam.min_x, cam.min_y, cam.max_x, cam.max_y = bounds
+    sf = np.asarray(scale_factors, np.float32)
+    cam.n_levels = len(sf)
+    cam.log_scale_factor = float(np.log(np.float32(sf[1] if len(sf) > 1 else 1.2), dtype=np.float32))
+    for i, v in enumerate(sf):
+        cam.scale_factors[i] = float(v)
+    return cam
 
 
 def project_last_frame(Tcw, K, bounds, world_pts, last_octaves, last_angles, valid, observed, scale_factors,

@@ -512,3 +512,82 @@ def test_undistort_keypoints_inverts_the_brown_model(oracle):
         # diverges in the extreme corners) -- the known behaviour of the 5-iteration cv::undistortPoints
         assert np.median(err) < 0.01 and np.percentile(err, 60) < 0.05
         assert np.abs(un["x"] - k["x"]).max() > 1.0                      # and it did move the points
+
+
+# ---- projection prologues (src/ORBmatcher.cc:1339-1390, src/Frame.cc:269-325, src/MapPoint.cc:400-418) ---------
+def _cam(M, bounds=(0.0, 0.0, 1241.0, 376.0), mbf=386.1448):
+    sf = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))])).astype(np.float32)
+    return M.make_camera(718.856, 718.856, 607.1928, 185.2157, bounds, sf, mbf=mbf, mb=mbf / 718.856), sf
+
+
+def test_det_logf_is_the_correctly_rounded_log(oracle):
+    import math
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(1e-4, 1e4, 50000), 2.0 ** rng.uniform(-120, 120, 5000), [1.0, 1.2, 0.5, 2.0]])
+    for x in xs.astype(np.float32):
+        assert np.float32(oracle.det_logf(x)) == np.float32(math.log(float(x))), x
+    assert oracle.det_logf(1.0) == 0.0
+
+
+def test_project_last_frame_hand_worked(oracle):
+    """Identity rotation, translation (0.5, 0, 0): a point at (1, 2, 10) projects to fx*1.5/10+cx, fy*2/10+cy."""
+    from orb_slam2_comment_amd import matcher as M, capi
+    cam, sf = _cam(M)
+    f32 = np.float32
+    Tlw = np.eye(4, dtype=f32)
+    Tcw = np.eye(4, dtype=f32); Tcw[0, 3] = 0.5
+    keys = np.zeros(5, oracle.KP_DTYPE)
+    keys["octave"] = [0, 3, 7, 2, 1]
+    keys["angle"] = [10, 20, 30, 40, 50]
+    world = np.array([[1, 2, 10], [0, 0, -4], [1000, 0, 5], [0, 0, 8], [0.25, -0.5, 4]], f32)
+    flags = np.array([3, 1, 1, 0, 1], np.uint8)          # point 3 has no map point; only point 0 is "observed"
+    q = oracle.project_last_frame(cam, Tcw, Tlw, world, flags, keys, 15.0, True)
+    assert q["valid"].tolist() == [1, 0, 0, 0, 1]         # behind the camera / outside the image / absent
+    u0 = f32(f32(f32(f32(718.856) * f32(1.5)) * f32(0.1)) + f32(607.1928))
+    v0 = f32(f32(f32(f32(718.856) * f32(2.0)) * f32(0.1)) + f32(185.2157))
+    assert q["u"][0] == u0 and q["v"][0] == v0
+    assert q["radius"][0] == f32(15.0) * sf[0] and q["radius"][4] == f32(15.0) * sf[1]
+    assert (q["min_level"][0], q["max_level"][0]) == (-1, 1) and (q["min_level"][4], q["max_level"][4]) == (0, 2)
+    assert q["ur"][0] == f32(u0 - f32(f32(386.1448) * f32(0.1)))
+    assert q["observed"].tolist() == [1, 0, 0, 0, 0] and q["angle"][4] == 50 and q["level_aux"][4] == 1
+    # stereo, camera moved forward by 2 m (> mb = 0.537 m): bForward -> levels [octave, open)
+    Tf = np.eye(4, dtype=f32); Tf[2, 3] = -2.0
+    qf = oracle.project_last_frame(cam, Tf, Tlw, world, flags, keys, 7.0, False)
+    assert (qf["min_level"][0], qf["max_level"][0]) == (0, -1) and (qf["min_level"][4], qf["max_level"][4]) == (1, -1)
+    Tb = np.eye(4, dtype=f32); Tb[2, 3] = 2.0
+    qb = oracle.project_last_frame(cam, Tb, Tlw, world, flags, keys, 7.0, False)
+    assert (qb["min_level"][4], qb["max_level"][4]) == (0, 1)
+    qm = oracle.project_last_frame(cam, Tf, Tlw, world, flags, keys, 7.0, True)      # bMono ignores the motion
+    assert (qm["min_level"][4], qm["max_level"][4]) == (0, 2)
+
+
+def test_frustum_queries_hand_worked(oracle):
+    """Camera at the origin looking down +z.  A point at distance 10 with mfMaxDistance 10*1.2^3 has
+    ratio 1.728 = 1.2^3 -> ceil(log(ratio)/log(1.2)) = 3 (or 4 if the float log lands just above)."""
+    from orb_slam2_comment_amd import matcher as M
+    cam, sf = _cam(M)
+    f32 = np.float32
+    T = np.eye(4, dtype=f32)
+    world = np.array([[0, 0, 10], [0, 0, 10], [0, 0, 10], [0, 0, -1], [0, 0, 10], [300, 0, 10], [0, 0, 10]], f32)
+    normal = np.array([[0, 0, 1], [0, 0, 1], [1, 0, 0], [0, 0, 1], [0, 0, 1], [0, 0, 1], [0.06, 0, 1]], f32)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    max_d = np.array([10 * 1.2 ** 2.5, 100.0, 20, 20, 5.0, 20, 10.0], f32)
+    min_d = np.array([1, 1, 1, 1, 1, 1, 1], f32)
+    flags = np.array([1, 3, 1, 1, 1, 1, 1], np.uint8)
+    q, vc = oracle.frustum_queries(cam, T, world, normal, max_d, min_d, flags, 0.5, 1.0)
+    #  0: in view, level ceil(2.5) = 3        1: ratio 10 -> ceil(12.6) clamped to 7     2: viewed from the side (cos 0)
+    #  3: behind     4: beyond 1.2*mfMaxDistance = 6      5: outside the image      6: cos(3.4 deg) = 0.9982 > 0.998
+    assert q["valid"].tolist() == [1, 1, 0, 0, 0, 0, 1]
+    assert q["level_aux"][0] == 3 and q["level_aux"][1] == 7 and q["level_aux"][6] == 0
+    assert (q["min_level"][0], q["max_level"][0]) == (2, 3)
+    assert q["u"][0] == f32(607.1928) and q["v"][0] == f32(185.2157)
+    assert vc[0] == 1.0 and q["radius"][0] == f32(2.5) * sf[3] and q["radius"][1] == f32(2.5) * sf[7]
+    assert q["ur"][0] == f32(f32(607.1928) - f32(f32(386.1448) * f32(0.1)))
+    assert q["observed"].tolist() == [0, 1, 0, 0, 0, 0, 0]
+    n6 = normal[6].astype(np.float64)
+    assert abs(vc[6] - n6[2]) < 1e-6 and vc[6] > 0.998 and q["radius"][6] == f32(2.5) * sf[0]
+    # th != 1 multiplies the radius (bFactor), a sideways normal at 4 deg falls to the wide window
+    normal[6] = [0.07, 0, 1]; normal[6] /= np.linalg.norm(normal[6])
+    q3, vc3 = oracle.frustum_queries(cam, T, world, normal, max_d, min_d, flags, 0.5, 3.0)
+    assert q3["radius"][0] == f32(f32(2.5) * f32(3.0)) * sf[3]
+    assert vc3[6] < 0.998 and q3["radius"][6] == f32(f32(4.0) * f32(3.0)) * sf[0]

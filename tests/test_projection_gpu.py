@@ -1,0 +1,279 @@
+"""Projection prologues on the device (src/ORBmatcher.cc:1339-1390, src/Frame.cc:269-325, src/MapPoint.cc:400-418)
+against the oracle: every field of every query record bit-identical (the float operation order is explicit on both
+sides), host and device-resident forms, and the fused Tracking step (prologue + SearchByProjection) against
+oracle prologue + oracle search."""
+import numpy as np
+import pytest
+
+from helpers import frame_bounds, synth_frame
+
+pytestmark = pytest.mark.gpu
+
+KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, KITTI_BF = 718.856, 718.856, 607.1928, 185.2157, 386.1448
+
+
+@pytest.fixture(scope="module")
+def env(oracle):
+    import orb_slam2_comment_amd as pkg
+    from orb_slam2_comment_amd import matcher as M
+    return pkg, M, oracle
+
+
+def _pose(rng, small=True):
+    """A rigid pose [R | t] with a small (or large) rotation, float32 4x4."""
+    a = rng.normal(0, 0.02 if small else 0.6, 3)
+    th = np.linalg.norm(a)
+    k = a / max(th, 1e-12)
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = R.astype(np.float32)
+    T[:3, 3] = rng.normal(0, 0.3 if small else 2.0, 3).astype(np.float32)
+    return T
+
+
+def _assert_queries_equal(a, b, what=""):
+    for f in a.dtype.names:
+        assert np.array_equal(a[f].view(np.int32), b[f].view(np.int32)), "%s field %s differs at %s" % (
+            what, f, np.nonzero(a[f].view(np.int32) != b[f].view(np.int32))[0][:5])
+
+
+def _back_project(k, z, cam, Tlw):
+    """World positions of last-frame keypoints at depths z (float32, any consistent recipe will do)."""
+    xc = (k["x"] - np.float32(cam.cx)) * z / np.float32(cam.fx)
+    yc = (k["y"] - np.float32(cam.cy)) * z / np.float32(cam.fy)
+    Pc = np.stack([xc, yc, z], 1).astype(np.float64)
+    R, t = Tlw[:3, :3].astype(np.float64), Tlw[:3, 3].astype(np.float64)
+    return ((Pc - t) @ R).astype(np.float32)          # R^T (Pc - t)
+
+
+@pytest.mark.parametrize("mono,th,motion", [(True, 15, "small"), (False, 7, "small"), (False, 7, "forward"),
+                                            (False, 7, "backward"), (True, 30, "large")])
+def test_project_last_frame_matches_oracle(env, mono, th, motion):
+    pkg, M, O = env
+    rng = np.random.default_rng(int(mono) + 2 * int(th) + 100 * ["small", "forward", "backward", "large"].index(motion))
+    ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    img = synth_frame(4)
+    k_last, _ = ext(img)
+    sf = ext.GetScaleFactors()
+    cam = M.make_camera(KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, frame_bounds(img), sf, mbf=KITTI_BF,
+                        mb=KITTI_BF / KITTI_FX)
+    Tlw = _pose(rng)
+    Tcw = _pose(rng, small=motion != "large")
+    if motion in ("forward", "backward"):                 # camera centre moves along the last frame's z by > mb
+        Tcw = Tlw.copy()
+        Tcw[2, 3] += np.float32(-1.5 if motion == "forward" else 1.5)
+    z = rng.uniform(3, 60, len(k_last)).astype(np.float32)
+    z[::17] = -z[::17]                                    # some points behind the camera
+    X = _back_project(k_last, z, cam, Tlw)
+    flags = (rng.random(len(k_last)) < 0.85).astype(np.uint8) * pkg.capi.POINT_PRESENT
+    flags |= (rng.random(len(k_last)) < 0.7).astype(np.uint8) * pkg.capi.POINT_OBSERVED
+    m = pkg.ORBmatcher(0.9, True)
+    q = m.ProjectLastFrame(cam, Tcw, Tlw, X, flags, k_last, th, mono)
+    oq = O.project_last_frame(cam, Tcw, Tlw, X, flags, k_last, th, mono)
+    _assert_queries_equal(q, oq, motion)
+    assert 0 < q["valid"].sum() < len(q)
+    if motion == "forward":
+        assert (q["max_level"][q["valid"] == 1] == -1).all()
+    if motion == "backward":
+        assert (q["min_level"][q["valid"] == 1] == 0).all()
+    if motion == "small":
+        v = q["valid"] == 1
+        assert np.array_equal(q["min_level"][v], k_last["octave"][v] - 1)
+    # the pure-Python statement of the same arithmetic (host mirror) agrees on the projected coordinates
+    bF = (not mono) and motion == "forward"
+    bB = (not mono) and motion == "backward"
+    pq = M.project_last_frame(Tcw, (cam.fx, cam.fy, cam.cx, cam.cy), (cam.min_x, cam.min_y, cam.max_x, cam.max_y), X,
+                              k_last["octave"], k_last["angle"], flags & 1, (flags >> 1) & 1, sf, th, mbf=cam.mbf,
+                              bForward=bF, bBackward=bB)
+    v = q["valid"] == 1
+    assert np.array_equal(pq["valid"], q["valid"]) and np.array_equal(pq["u"][v], q["u"][v]) and np.array_equal(pq["ur"][v], q["ur"][v])
+
+
+@pytest.mark.parametrize("th,seed", [(1.0, 1), (3.0, 2), (5.0, 3)])
+def test_frustum_queries_match_oracle(env, th, seed):
+    """Frame::isInFrustum + PredictScale + search window for a synthetic local map: points in front / behind / outside
+    the image / outside the scale-invariance range / seen from the side."""
+    pkg, M, O = env
+    rng = np.random.default_rng(seed)
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    sf = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))])).astype(np.float32)
+    cam = M.make_camera(KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, (0.0, 0.0, 1241.0, 376.0), sf, mbf=KITTI_BF,
+                        mb=KITTI_BF / KITTI_FX)
+    n = 9000                                                # a local map larger than 4096 points
+    Tcw = _pose(rng, small=False)
+    R, t = Tcw[:3, :3].astype(np.float64), Tcw[:3, 3].astype(np.float64)
+    z = rng.uniform(-5, 80, n)
+    u = rng.uniform(-200, 1441, n)
+    v = rng.uniform(-100, 476, n)
+    Pc = np.stack([(u - KITTI_CX) * z / KITTI_FX, (v - KITTI_CY) * z / KITTI_FY, z], 1)
+    X = ((Pc - t) @ R).astype(np.float32)
+    Ow = -(R.T @ t)
+    view = X.astype(np.float64) - Ow
+    nrm = view / np.maximum(np.linalg.norm(view, axis=1, keepdims=True), 1e-9)
+    nrm = nrm + rng.normal(0, 0.6, (n, 3)) * (rng.random((n, 1)) < 0.5)     # half the normals are off-axis
+    nrm = (nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-9)).astype(np.float32)
+    d = np.linalg.norm(view, axis=1)
+    max_d = (d * rng.uniform(0.5, 6.0, n)).astype(np.float32)                # some points too close / too far
+    min_d = (max_d / np.float32(1.2 ** 7)).astype(np.float32)
+    flags = (rng.random(n) < 0.9).astype(np.uint8) * pkg.capi.POINT_PRESENT
+    flags |= (rng.random(n) < 0.8).astype(np.uint8) * pkg.capi.POINT_OBSERVED
+    m = pkg.ORBmatcher(0.8, True)
+    q, vc = m.FrustumQueries(cam, Tcw, X, nrm, max_d, min_d, flags, 0.5, th)
+    oq, ovc = O.frustum_queries(cam, Tcw, X, nrm, max_d, min_d, flags, 0.5, th)
+    _assert_queries_equal(q, oq)
+    assert np.array_equal(vc.view(np.int32), ovc.view(np.int32))
+    vis = q["valid"] == 1
+    assert 300 < vis.sum() < n // 2
+    assert set(np.unique(q["level_aux"][vis])) == set(range(8))             # every predicted level occurs
+    assert (vc[vis] >= 0.5).all() and (q["min_level"][vis] == q["level_aux"][vis] - 1).all()
+    # independent float64 statement of the visibility decision (agrees except within rounding of a threshold)
+    zc = (X.astype(np.float64) @ R.T + t)[:, 2]
+    uu = KITTI_FX * (X.astype(np.float64) @ R.T + t)[:, 0] / zc + KITTI_CX
+    vv = KITTI_FY * (X.astype(np.float64) @ R.T + t)[:, 1] / zc + KITTI_CY
+    cosv = (view * nrm).sum(1) / d
+    ref = (flags & 1).astype(bool) & (zc >= 0) & (uu >= 0) & (uu <= 1241) & (vv >= 0) & (vv <= 376) & \
+        (d >= 0.8 * min_d) & (d <= 1.2 * max_d) & (cosv >= 0.5)
+    assert (ref != vis).sum() <= 5
+
+
+def test_device_forms_and_fused_tracking_step(env):
+    """orbhip_project_last_frame_device / orbhip_frustum_queries_device reproduce the host forms; the fused
+    orbhip_track_last_frame_device equals oracle prologue + oracle SearchByProjection for every pair."""
+    torch = pytest.importorskip("torch")
+    pkg, M, O = env
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda", 0)
+    ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    frames = np.stack([synth_frame(1 + (i // 2) % 3, shift_xy=(3 * (i % 2), 0)) for i in range(6)])   # (last, cur) x 3
+    B, H, W = frames.shape
+    cap = ext.capacity(H, W)
+    d_img = torch.from_numpy(frames).to(dev)
+    d_k = torch.zeros((B, cap, 7), dtype=torch.int32, device=dev)
+    d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ext.set_stream(st)
+    ext.extract_batch_device(d_img.data_ptr(), B, H, W, d_k.data_ptr(), d_d.data_ptr(), cap, d_n.data_ptr())
+    torch.cuda.synchronize()
+    kps = d_k.cpu().numpy().view(np.uint8).reshape(B, cap, 28).copy().view(pkg.KP_DTYPE).reshape(B, cap)
+    desc, n = d_d.cpu().numpy(), d_n.cpu().numpy()
+    sf = ext.GetScaleFactors()
+    cam = M.make_camera(KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, frame_bounds(frames[0]), sf, mbf=KITTI_BF,
+                        mb=KITTI_BF / KITTI_FX)
+    pairs = B // 2
+    zc = np.float32(12.0)
+    Tlw = np.stack([np.eye(4, dtype=np.float32) for _ in range(pairs)])
+    Tcw = Tlw.copy()
+    Tcw[:, 0, 3] = np.float32(3.0) * zc / np.float32(KITTI_FX)     # 3-px shift of every point at depth zc
+    world = np.zeros((B, cap, 3), np.float32)
+    flags = np.zeros((B, cap), np.uint8)
+    for p in range(pairs):
+        fl = 2 * p
+        kl = kps[fl, :n[fl]]
+        world[fl, :n[fl]] = _back_project(kl, np.full(n[fl], zc, np.float32), cam, Tlw[p])
+        flags[fl, :n[fl]] = (rng.random(n[fl]) < 0.9) * pkg.capi.POINT_PRESENT + (rng.random(n[fl]) < 0.7) * pkg.capi.POINT_OBSERVED
+    taken = (rng.random((pairs, cap)) < 0.05).astype(np.uint8)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    d_Tcw, d_Tlw = t(Tcw[:, :3, :].reshape(pairs, 12)), t(Tlw[:, :3, :].reshape(pairs, 12))
+    d_world, d_flags, d_taken = t(world), t(flags), t(taken)
+    d_q = torch.zeros((pairs, cap, 10), dtype=torch.int32, device=dev)
+    d_nq = torch.zeros(pairs, dtype=torch.int32, device=dev)
+    d_assign = torch.zeros((pairs, cap), dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(pairs, dtype=torch.int32, device=dev)
+    for mono, th in ((True, 15.0), (False, 7.0)):
+        m = pkg.ORBmatcher(0.9, True)
+        m.set_stream(st)
+        m.ProjectLastFrameDevice(pairs, cam, d_Tcw.data_ptr(), d_Tlw.data_ptr(), d_k.data_ptr(), d_n.data_ptr(), cap, 0, 2,
+                                 d_world.data_ptr(), d_flags.data_ptr(), th, mono, d_q.data_ptr(), d_nq.data_ptr())
+        m.TrackLastFrameDevice(pairs, cam, d_Tcw.data_ptr(), d_Tlw.data_ptr(), d_k.data_ptr(), d_d.data_ptr(), d_n.data_ptr(),
+                               cap, 1, 2, 0, 2, d_world.data_ptr(), d_flags.data_ptr(), th, mono, d_assign.data_ptr(),
+                               d_nm.data_ptr(), d_taken=d_taken.data_ptr())
+        torch.cuda.synchronize()
+        qd = d_q.cpu().numpy().view(np.uint8).reshape(pairs, cap, 40).copy().view(pkg.QUERY_DTYPE).reshape(pairs, cap)
+        assign, nm = d_assign.cpu().numpy(), d_nm.cpu().numpy()
+        assert np.array_equal(d_nq.cpu().numpy(), n[0::2])
+        for p in range(pairs):
+            fl, fc = 2 * p, 2 * p + 1
+            oq = O.project_last_frame(cam, Tcw[p], Tlw[p], world[fl, :n[fl]], flags[fl, :n[fl]], kps[fl, :n[fl]], th, mono)
+            _assert_queries_equal(qd[p, :n[fl]], oq, "pair %d" % p)
+            keep = []
+            ov = O.make_frame(kps[fc, :n[fc]], desc[fc, :n[fc]], None, frame_bounds(frames[0]), sf, keep)
+            on, oassign = O.search_by_projection_frame(ov, oq, desc[fl, :n[fl]], taken[p, :n[fc]], True)
+            assert nm[p] == on and np.array_equal(assign[p, :n[fc]], oassign), "pair %d" % p
+            assert on > 300
+    # frustum, device-resident: two frames with different poses and point counts
+    pc = 5000
+    Tf = np.stack([_pose(rng, small=False) for _ in range(2)])
+    npts = np.array([5000, 3100], np.int32)
+    X = rng.normal(0, 20, (2, pc, 3)).astype(np.float32)
+    Nn = rng.normal(0, 1, (2, pc, 3)).astype(np.float32)
+    Nn /= np.linalg.norm(Nn, axis=2, keepdims=True)
+    mx = rng.uniform(5, 120, (2, pc)).astype(np.float32)
+    mn = (mx / np.float32(3.58)).astype(np.float32)
+    fg = (rng.random((2, pc)) < 0.9).astype(np.uint8) + 2 * (rng.random((2, pc)) < 0.5).astype(np.uint8)
+    d_fq = torch.zeros((2, pc, 10), dtype=torch.int32, device=dev)
+    d_vc = torch.zeros((2, pc), dtype=torch.float32, device=dev)
+    m = pkg.ORBmatcher(0.8, True)
+    m.set_stream(st)
+    keepalive = [t(Tf[:, :3, :].reshape(2, 12)), t(npts), t(X), t(Nn), t(mx), t(mn), t(fg)]
+    m.FrustumQueriesDevice(2, cam, keepalive[0].data_ptr(), pc, keepalive[1].data_ptr(), keepalive[2].data_ptr(),
+                           keepalive[3].data_ptr(), keepalive[4].data_ptr(), keepalive[5].data_ptr(), keepalive[6].data_ptr(),
+                           0.5, 3.0, d_fq.data_ptr(), d_vc.data_ptr())
+    torch.cuda.synchronize()
+    fq = d_fq.cpu().numpy().view(np.uint8).reshape(2, pc, 40).copy().view(pkg.QUERY_DTYPE).reshape(2, pc)
+    vc = d_vc.cpu().numpy()
+    for f in range(2):
+        k = npts[f]
+        oq, ovc = O.frustum_queries(cam, Tf[f], X[f, :k], Nn[f, :k], mx[f, :k], mn[f, :k], fg[f, :k], 0.5, 3.0)
+        _assert_queries_equal(fq[f, :k], oq, "frame %d" % f)
+        assert np.array_equal(vc[f, :k].view(np.int32), ovc.view(np.int32))
+        assert oq["valid"].sum() > 20
+
+
+def test_search_for_initialization_device_matches_oracle(env):
+    """configs[4] shape: 752x480 @2000, windowSize 100, nnratio 0.9 (src/Tracking.cc:599-600), batched on the device;
+    second call continues from the updated vbPrevMatched like Tracking does frame after frame."""
+    torch = pytest.importorskip("torch")
+    pkg, M, O = env
+    dev = torch.device("cuda", 0)
+    EW, EH = 752, 480
+    frames = np.stack([synth_frame(20 + (i // 2) % 3, EW, EH, shift_xy=(5 * (i % 2), 2 * (i % 2))) for i in range(6)])
+    B = len(frames)
+    ext = pkg.ORBextractor(2000, 1.2, 8, 20, 7)
+    cap = ext.capacity(EH, EW)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ext.set_stream(st)
+    d_img = torch.from_numpy(frames).to(dev)
+    d_k = torch.zeros((B, cap, 7), dtype=torch.int32, device=dev)
+    d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    ext.extract_batch_device(d_img.data_ptr(), B, EH, EW, d_k.data_ptr(), d_d.data_ptr(), cap, d_n.data_ptr())
+    torch.cuda.synchronize()
+    kps = d_k.cpu().numpy().view(np.uint8).reshape(B, cap, 28).copy().view(pkg.KP_DTYPE).reshape(B, cap)
+    desc, n = d_d.cpu().numpy(), d_n.cpu().numpy()
+    sf = ext.GetScaleFactors()
+    pairs = B // 2
+    d_prev = torch.zeros((pairs, cap, 2), dtype=torch.float32, device=dev)
+    d_m12 = torch.zeros((pairs, cap), dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(pairs, dtype=torch.int32, device=dev)
+    bounds = frame_bounds(frames[0])
+    for ori in (True, False):
+        m = pkg.ORBmatcher(0.9, ori)
+        m.set_stream(st)
+        opm = [None] * pairs
+        for rnd in range(2):
+            m.SearchForInitializationDevice(pairs, d_k.data_ptr(), d_d.data_ptr(), d_n.data_ptr(), cap, 0, 2, 1, 2, bounds,
+                                            rnd > 0, d_prev.data_ptr(), 100, d_m12.data_ptr(), d_nm.data_ptr())
+            torch.cuda.synchronize()
+            m12, nm, prev = d_m12.cpu().numpy(), d_nm.cpu().numpy(), d_prev.cpu().numpy()
+            for p in range(pairs):
+                f1, f2 = 2 * p, 2 * p + 1
+                keep = []
+                o1 = O.make_frame(kps[f1, :n[f1]], desc[f1, :n[f1]], None, bounds, sf, keep)
+                o2 = O.make_frame(kps[f2, :n[f2]], desc[f2, :n[f2]], None, bounds, sf, keep)
+                pm0 = np.stack([kps[f1, :n[f1]]["x"], kps[f1, :n[f1]]["y"]], 1) if rnd == 0 else opm[p]
+                on, om12, opm[p] = O.search_for_initialization(o1, o2, pm0, 100, 0.9, ori)
+                assert nm[p] == on and np.array_equal(m12[p, :n[f1]], om12), (p, rnd, ori)
+                assert np.array_equal(prev[p, :n[f1]], opm[p])
+                assert on > 80

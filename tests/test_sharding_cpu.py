@@ -80,3 +80,21 @@ def test_gather_to_rank0_gloo_world2():
         p.join(60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_bench_self_launches_two_ranks_gloo_dry_run():
+    """`python bench.py --gpus 2` without a launcher environment brings up its own two ranks (before anything could
+    touch a GPU); with --dist-backend gloo --dry-run the pair sharding and the gather run on fabricated slots."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--dry-run",
+                        "--steps", "2", "--warmup", "0", "--frames-per-gpu", "8"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["gather_verified"] is True
+    assert out["config"]["pairs_per_rank"] == 4 and out["config"]["parallelism"] == "pair-sharded x2"

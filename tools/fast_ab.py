@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--calls", type=int, default=20)
-    ap.add_argument("--variants", default="1,0")
+    ap.add_argument("--variants", default="0,3,4")
     ap.add_argument("--size", default="1241x376")
     ap.add_argument("--nfeatures", type=int, default=1000)
     args = ap.parse_args()
@@ -58,7 +58,7 @@ def main():
         sig = (d_n.cpu().numpy().copy(), d_d.cpu().numpy().copy(), d_k.cpu().numpy().copy())
         if ref is None:
             ref = sig
-        else:
+        elif v < 3:
             n = ref[0]
             same = np.array_equal(n, sig[0]) and all(np.array_equal(ref[1][b, :n[b]], sig[1][b, :n[b]]) and
                                                       np.array_equal(ref[2][b, :n[b]], sig[2][b, :n[b]]) for b in range(B))
@@ -76,6 +76,19 @@ def main():
             res[v].append(ext.stage_times_us())
             ext.set_profiling(False)
     out = {}
+    if 2 in variants:                          # stamped diagnostic build: shares of the wave lifetime per phase
+        L.orbhip_dev_set_fast_variant(ext._h, 2)
+        z = (C.c_ulonglong * 8)()
+        torch.cuda.synchronize()
+        L.orbhip_dev_fast_stamps(z)
+        run()
+        torch.cuda.synchronize()
+        L.orbhip_dev_fast_stamps(z)
+        waves = max(1, z[7])
+        names = ["prologue", "staging", "dense", "score", "nms_emit"]
+        tot = float(sum(z[i] for i in range(5)))
+        print(json.dumps({"stamps_cycles_per_wave": {names[i]: round(z[i] / waves, 1) for i in range(5)},
+                          "shares": {names[i]: round(z[i] / tot, 3) for i in range(5)}, "waves": int(waves)}), file=sys.stderr)
     for v in variants:
         out[str(v)] = {k: {"median": round(float(np.median([r[k] for r in res[v]])), 2),
                            "min": round(float(np.min([r[k] for r in res[v]])), 2)} for k in res[v][0]}
