@@ -72,11 +72,7 @@ def cpu_baseline(frames, budget_s=20.0):
     except Exception:
         flags = "-O2 (prebuilt; native rebuild failed)"
     from orb_slam2_comment_amd import matcher as M
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count() or 1
-    cores = max(1, cores)
+    cores = host_cores()
     O.lib()
     sf = np.cumprod(np.concatenate([[np.float32(1)], np.full(NLEVELS - 1, np.float32(1.2))])).astype(np.float32)
     cam = M.make_camera(KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, (0.0, 0.0, float(W), float(H)), sf, mbf=KITTI_BF,
@@ -102,16 +98,19 @@ def cpu_baseline(frames, budget_s=20.0):
     t0 = time.perf_counter()
     nm = one_pair(warm, 0)                                              # single-thread estimate
     one = time.perf_counter() - t0
-    per_thread = int(max(2, min(200, budget_s / max(one, 1e-3))))      # ~budget_s of wall, all threads busy
     done = [0] * cores
+    t_end = [0.0]
 
-    def work(t):
+    def work(t):                                                        # time-bounded: every thread stops at the budget
         e = O.OracleExtractor(NFEAT, 1.2, NLEVELS, 20, 7)
-        for i in range(per_thread):
-            one_pair(e, (t * per_thread + i) % npairs)
+        i = 0
+        while time.perf_counter() < t_end[0]:
+            one_pair(e, (t * 7 + i) % npairs)
             done[t] += 2
+            i += 1
     th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
     t0 = time.perf_counter()
+    t_end[0] = t0 + budget_s
     for t in th:
         t.start()
     for t in th:
@@ -119,11 +118,34 @@ def cpu_baseline(frames, budget_s=20.0):
     dt = time.perf_counter() - t0
     total = sum(done)
     return {"value": round(total / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames 1241x376 = %d (last, cur) pairs (%d pairs per thread x %d threads, all host cores), "
-                      "extract + projection + SearchByProjection per pair (%d matches on pair 0), %.1f s wall; scalar C "
+            "sample": "%d frames 1241x376 = %d (last, cur) pairs on %d threads (every core this process may use) for %.1f s: "
+                      "extract + projection + SearchByProjection per pair (%d matches on pair 0); scalar C "
                       "port built %s -ffp-contract=off on this host, not OpenCV SIMD" %
-                      (total, total // 2, per_thread, cores, nm, dt, flags),
+                      (total, total // 2, cores, dt, nm, flags),
             "single_thread_frames_per_s": round(2.0 / one, 2)}
+
+
+def host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, n)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -256,8 +278,8 @@ def main():
     for h in range(Hn):
         e = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
         mt = ORBmatcher(0.9, True, device=local_rank)
-        st = torch.cuda.current_stream(dev) if Hn == 1 else torch.cuda.Stream(dev)
-        e.set_stream(st.cuda_stream)             # launches go to a torch-owned stream
+        st = torch.cuda.Stream(dev)              # one real (non-null) stream per pipeline: a null handle would mean
+        e.set_stream(st.cuda_stream)             # "the handle's own stream", and extractor and matcher must share one
         mt.set_stream(st.cuda_stream)
         exts.append(e); mts.append(mt); streams.append(st)
     ext = exts[0]
@@ -408,6 +430,8 @@ def main():
     assert int(o["st"].abs().sum().item()) == 0 and n_host.min() > 0, "extraction failed"
     assert nm_host.min() > 100, "SearchByProjection found too few matches: the synthetic pairs are broken"
 
+    if rank == 0:
+        print("[bench] headline done: %.1f frames/s; secondary legs ..." % (B * world * reps * args.steps / dt_long), file=sys.stderr, flush=True)
     secondary = None
     if not args.no_secondary and world == 1 and not multi:
         secondary = secondary_legs(args, torch, dev, local_rank, exts, streams, obuf[0], d_img, cap, splits, offs, psplit, extract_all)
@@ -418,9 +442,10 @@ def main():
         fps_k = B * world * args.steps / dt_k                   # exactly K steps
         # dominant single kernel: largest HIP-event time among the one-launch stages (the pyramid stage is 8
         # dependent launches, the matching 4 small ones)
-        kern = max(("fast", "blur", "describe", "octree"), key=lambda k: stage[k])
-        if ALGO_BYTES[kern] == 0:
-            kern = max(("fast", "blur", "describe"), key=lambda k: stage[k])
+        kern = max(("fast", "blur", "describe"), key=lambda k: stage[k])
+        if stage["fast"] >= 0.8 * stage[kern]:
+            kern = "fast"     # rocprofv3 --stats: k_fast_cells has the largest total time of any single kernel; with two
+                              # pipelines interleaved the HBM-bound blur is stretched more than the VALU-bound FAST
         algo = ALGO_BYTES[kern] * Bh                # frames per launch of one handle
         achieved = algo / (stage[kern] * 1e-6) / 1e9
         traffic, valu = None, None
@@ -472,6 +497,7 @@ def main():
         if secondary:
             out.update(secondary)
         if not args.no_cpu_baseline and world == 1:
+            print("[bench] GPU legs done; cpu_baseline (~25 s) ...", file=sys.stderr, flush=True)
             out["cpu_baseline"] = cpu_baseline(frames[:16])
         else:
             out["cpu_baseline"] = None
@@ -510,7 +536,7 @@ def secondary_legs(args, torch, dev, local_rank, exts, streams, o, d_img, cap, s
                                    "(%d pipelines), nothing else" % (B, len(exts)),
                            "ms_per_step": round(dt / (reps * args.steps) * 1e3, 4), "timed_s": round(dt, 3), "stage_us": st}
 
-    cur = torch.cuda.current_stream(dev)
+    cur = torch.cuda.Stream(dev)               # every handle of the legs below launches on this one stream
     mt = ORBmatcher(0.9, True, device=local_rank)
     mt.set_stream(cur.cuda_stream)
     # ---- configs[2]: stereo front-end: extract left+right + Frame::ComputeStereoMatches --------------------------

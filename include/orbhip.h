@@ -95,7 +95,9 @@ int orbhip_extract(orbhip_extractor *e, const uint8_t *image, int rows, int cols
                    orbhip_keypoint *kps, uint8_t *desc, int cap, int *n);
 
 /* Batch of `batch` same-size frames, host buffers.  Frame b starts at
- * images + b*frame_stride; outputs of frame b at kps + b*cap, desc + b*cap*32, n[b]. */
+ * images + b*frame_stride; outputs of frame b at kps + b*cap, desc + b*cap*32, n[b].
+ * ORBHIP_E_CAPACITY (cap smaller than orbhip_extractor_capacity()): every frame's n[b] <= cap and its first n[b]
+ * keypoints / descriptors are still delivered (truncated in output order) before the error is returned. */
 int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, int rows, int cols,
                          int stride, size_t frame_stride, orbhip_keypoint *kps, uint8_t *desc,
                          int cap, int32_t *n);
@@ -177,7 +179,12 @@ int orbhip_search_for_initialization(orbhip_matcher *m, const orbhip_frame_view 
 
 /* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) after projection.
  * q[nq], qdesc[nq*32] = pMP->GetDescriptor(); taken[n] (may be NULL): slot already holds an
- * observed map point.  assign[n] out: query index now held by each current keypoint or -1. */
+ * observed map point.  assign[n] out: query index now held by each current keypoint or -1.
+ * Sizes (this and the points / keyframe / sim3 forms below): any n and nq.  Queries with valid == 0 are dropped
+ * on the host before anything is staged (a local map or a loop-closing point set is mostly such entries); up to
+ * 4096 train keypoints and 4096 VALID queries the resolve state is LDS resident, beyond that it moves to an HBM
+ * workspace (slower, same results).  Only orbhip_search_for_initialization keeps a hard limit (4096 keypoints per
+ * frame, ORBHIP_E_CAPACITY beyond): its match stealing is replayed by one wavefront over LDS state. */
 int orbhip_search_by_projection_frame(orbhip_matcher *m, const orbhip_frame_view *cur,
                                       const orbhip_query *q, const uint8_t *qdesc, int nq,
                                       const uint8_t *taken, int32_t *assign, int check_ori,
@@ -345,7 +352,8 @@ int orbhip_vocabulary_transform_device(orbhip_vocabulary *v, int frames, const v
  * orbhip_keypoint, d_desc [pairs][cap][32], d_n [pairs] int32; optional d_u_right [pairs][cap] float and
  * d_taken [pairs][cap] uint8.  Query side: d_q [pairs][qcap] orbhip_query, d_qdesc [pairs][qcap][32],
  * d_nq [pairs] int32.  The image bounds / grid scale are shared (one camera).  Outputs: d_assign [pairs][cap]
- * int32 (query index held by each keypoint or -1), d_nmatches [pairs] int32.  cap, qcap <= 4096. */
+ * int32 (query index held by each keypoint or -1), d_nmatches [pairs] int32.  No size limit: up to 4096 keypoints
+ * and queries the resolve state is LDS resident, beyond that it lives in an HBM workspace (slower, same results). */
 int orbhip_search_by_projection_frame_device(orbhip_matcher *m, int pairs, const void *d_kps, const void *d_desc,
                                              const void *d_n, int cap, const void *d_u_right, const void *d_taken,
                                              float min_x, float min_y, float grid_inv_w, float grid_inv_h,
@@ -413,7 +421,7 @@ int orbhip_frustum_queries(orbhip_matcher *m, const orbhip_camera *cam, const fl
  * (Tracking::TrackWithMotionModel's matching step, src/Tracking.cc:880-885): the queries' descriptors are the last
  * frame's (the tracked map points were created from / last seen in it); optional d_u_right [frames][cap] float
  * (indexed by the current frame) and d_taken [pairs][cap] uint8; outputs d_assign [pairs][cap] int32 (last-frame
- * keypoint index now held by each current keypoint or -1), d_nmatches [pairs] int32.  cap <= 4096. */
+ * keypoint index now held by each current keypoint or -1), d_nmatches [pairs] int32. */
 int orbhip_project_last_frame_device(orbhip_matcher *m, int pairs, const orbhip_camera *cam, const void *d_Tcw,
                                      const void *d_Tlw, const void *d_kps, const void *d_n, int cap, int last_first,
                                      int last_step, const void *d_world, const void *d_flags, float th, int mono,

@@ -770,10 +770,32 @@ static int pos_in_grid(const oracle_frame *f, const oracle_kp *kp, int *px, int 
     return !(*px < 0 || *px >= FRAME_GRID_COLS || *py < 0 || *py >= FRAME_GRID_ROWS);
 }
 
-/* AssignFeaturesToGrid + GetFeaturesInArea, Frame.cc:230-245, 327-380.
- * The grid is rebuilt per call (oracle: clarity over speed). */
-int oracle_features_in_area(const oracle_frame *f, float x, float y, float r, int minLevel,
-                            int maxLevel, int32_t *out, int cap)
+/* AssignFeaturesToGrid (Frame.cc:230-245): mGrid as CSR -- cell c = ix * FRAME_GRID_ROWS + iy holds the indices
+ * items[start[c] .. start[c+1]) in insertion (= index) order.  The reference builds the grid once per Frame; the
+ * search functions below do the same at entry. */
+typedef struct { int32_t *start, *items; } oracle_grid;
+static void grid_build(const oracle_frame *f, oracle_grid *g)
+{
+    const int ncell = FRAME_GRID_COLS * FRAME_GRID_ROWS;
+    g->start = (int32_t *)calloc((size_t)ncell + 1, sizeof(int32_t));
+    g->items = (int32_t *)malloc(sizeof(int32_t) * (size_t)(f->n > 0 ? f->n : 1));
+    int32_t *cell = (int32_t *)malloc(sizeof(int32_t) * (size_t)(f->n > 0 ? f->n : 1));
+    for (int j = 0; j < f->n; ++j) {
+        int px, py;
+        cell[j] = pos_in_grid(f, &f->keys[j], &px, &py) ? px * FRAME_GRID_ROWS + py : -1;
+        if (cell[j] >= 0) g->start[cell[j] + 1]++;
+    }
+    for (int c = 0; c < ncell; ++c) g->start[c + 1] += g->start[c];
+    int32_t *fill = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncell);
+    memcpy(fill, g->start, sizeof(int32_t) * (size_t)ncell);
+    for (int j = 0; j < f->n; ++j) if (cell[j] >= 0) g->items[fill[cell[j]]++] = j;
+    free(fill); free(cell);
+}
+static void grid_free(oracle_grid *g) { free(g->start); free(g->items); g->start = g->items = NULL; }
+
+/* GetFeaturesInArea, Frame.cc:327-380 (cells ix outer / iy inner, insertion order inside a cell) */
+static int features_in_area_grid(const oracle_frame *f, const oracle_grid *g, float x, float y, float r, int minLevel,
+                                 int maxLevel, int32_t *out, int cap)
 {
     int n = 0;
     const int nMinCellX = cv_floor((x - f->min_x - r) * f->grid_inv_w) > 0 ? cv_floor((x - f->min_x - r) * f->grid_inv_w) : 0;
@@ -788,10 +810,10 @@ int oracle_features_in_area(const oracle_frame *f, float x, float y, float r, in
     if (nMaxCellY < 0) return 0;
     const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
     for (int ix = nMinCellX; ix <= nMaxCellX; ++ix)
-        for (int iy = nMinCellY; iy <= nMaxCellY; ++iy)
-            for (int j = 0; j < f->n; ++j) { /* insertion order within a cell = index order */
-                int px, py;
-                if (!pos_in_grid(f, &f->keys[j], &px, &py) || px != ix || py != iy) continue;
+        for (int iy = nMinCellY; iy <= nMaxCellY; ++iy) {
+            const int c = ix * FRAME_GRID_ROWS + iy;
+            for (int k = g->start[c]; k < g->start[c + 1]; ++k) {
+                const int j = g->items[k];
                 const oracle_kp *kp = &f->keys[j];
                 if (bCheckLevels) {
                     if (kp->octave < minLevel) continue;
@@ -800,6 +822,17 @@ int oracle_features_in_area(const oracle_frame *f, float x, float y, float r, in
                 const float distx = kp->x - x, disty = kp->y - y;
                 if (fabsf(distx) < r && fabsf(disty) < r) { if (n < cap) out[n] = j; ++n; }
             }
+        }
+    return n;
+}
+
+int oracle_features_in_area(const oracle_frame *f, float x, float y, float r, int minLevel,
+                            int maxLevel, int32_t *out, int cap)
+{
+    oracle_grid g;
+    grid_build(f, &g);
+    const int n = features_in_area_grid(f, &g, x, y, r, minLevel, maxLevel, out, cap);
+    grid_free(&g);
     return n;
 }
 
@@ -818,6 +851,8 @@ int oracle_search_for_initialization(const oracle_frame *f1, const oracle_frame 
                                      float *prev_matched, int32_t *matches12, int windowSize,
                                      float nnratio, int check_ori)
 {
+    oracle_grid grid;
+    grid_build(f2, &grid);
     int nmatches = 0;
     const int n1 = f1->n, n2 = f2->n;
     for (int i = 0; i < n1; ++i) matches12[i] = -1;
@@ -831,7 +866,7 @@ int oracle_search_for_initialization(const oracle_frame *f1, const oracle_frame 
         const oracle_kp *kp1 = &f1->keys[i1];
         int level1 = kp1->octave;
         if (level1 > 0) continue;
-        int nind = oracle_features_in_area(f2, prev_matched[2 * i1], prev_matched[2 * i1 + 1],
+        int nind = features_in_area_grid(f2, &grid, prev_matched[2 * i1], prev_matched[2 * i1 + 1],
                                            (float)windowSize, level1, level1, ind, n2);
         if (nind == 0) continue;
         const uint8_t *d1 = f1->desc + (size_t)i1 * 32;
@@ -874,7 +909,7 @@ int oracle_search_for_initialization(const oracle_frame *f1, const oracle_frame 
             prev_matched[2 * i1 + 1] = f2->keys[matches12[i1]].y;
         }
     free(hist); free(matchedDist); free(matches21); free(ind);
-    return nmatches;
+    grid_free(&grid); return nmatches;
 }
 
 /* SearchByProjection(Frame&,const Frame&,th,bMono), ORBmatcher.cc:1351-1469
@@ -883,6 +918,8 @@ int oracle_search_by_projection_frame(const oracle_frame *cur, const oracle_quer
                                       const uint8_t *qdesc, int nq, const uint8_t *taken_in,
                                       int32_t *assign, int check_ori)
 {
+    oracle_grid grid;
+    grid_build(cur, &grid);
     int nmatches = 0;
     const int n = cur->n;
     uint8_t *taken = (uint8_t *)malloc(n + 1);
@@ -893,7 +930,7 @@ int oracle_search_by_projection_frame(const oracle_frame *cur, const oracle_quer
     for (int i = 0; i < nq; ++i) {
         if (!q[i].valid) continue;
         const float u = q[i].u, v = q[i].v, radius = q[i].radius;
-        int nind = oracle_features_in_area(cur, u, v, radius, q[i].min_level, q[i].max_level, ind, n);
+        int nind = features_in_area_grid(cur, &grid, u, v, radius, q[i].min_level, q[i].max_level, ind, n);
         if (nind == 0) continue;
         const uint8_t *dMP = qdesc + (size_t)i * 32;
         int bestDist = 256, bestIdx2 = -1;
@@ -925,7 +962,7 @@ int oracle_search_by_projection_frame(const oracle_frame *cur, const oracle_quer
                 for (int j = 0; j < hs[i]; ++j) { assign[hist[i * nq + j]] = -1; nmatches--; }
     }
     free(taken); free(ind); free(hist);
-    return nmatches;
+    grid_free(&grid); return nmatches;
 }
 
 /* SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), ORBmatcher.cc:1472-1599 after the projection
@@ -934,6 +971,8 @@ int oracle_search_by_projection_frame(const oracle_frame *cur, const oracle_quer
 int oracle_search_by_projection_block(const oracle_frame *cur, const oracle_query *q, const uint8_t *qdesc, int nq,
                                       const uint8_t *taken_in, int32_t *assign, int max_dist, int check_ori)
 {
+    oracle_grid grid;
+    grid_build(cur, &grid);
     int nmatches = 0;
     const int n = cur->n;
     uint8_t *taken = (uint8_t *)malloc(n + 1);
@@ -943,7 +982,7 @@ int oracle_search_by_projection_block(const oracle_frame *cur, const oracle_quer
     for (int i = 0; i < n; ++i) { taken[i] = taken_in ? taken_in[i] : 0; assign[i] = -1; }
     for (int i = 0; i < nq; ++i) {
         if (!q[i].valid) continue;
-        int nind = oracle_features_in_area(cur, q[i].u, q[i].v, q[i].radius, q[i].min_level, q[i].max_level, ind, n);
+        int nind = features_in_area_grid(cur, &grid, q[i].u, q[i].v, q[i].radius, q[i].min_level, q[i].max_level, ind, n);
         if (nind == 0) continue;
         const uint8_t *dMP = qdesc + (size_t)i * 32;
         int bestDist = 256, bestIdx2 = -1;
@@ -971,7 +1010,7 @@ int oracle_search_by_projection_block(const oracle_frame *cur, const oracle_quer
                 for (int j = 0; j < hs[i]; ++j) { assign[hist[i * nq + j]] = -1; nmatches--; }
     }
     free(taken); free(ind); free(hist);
-    return nmatches;
+    grid_free(&grid); return nmatches;
 }
 
 /* Search loop of Fuse (ORBmatcher.cc:893-950; the Sim3 overload :1045-1075 has no chi2 gate) and of SearchBySim3
@@ -979,13 +1018,15 @@ int oracle_search_by_projection_block(const oracle_frame *cur, const oracle_quer
 void oracle_search_best_in_window(const oracle_frame *kf, const oracle_query *q, const uint8_t *qdesc, int nq,
                                   const float *inv_sigma2, int32_t *best_idx, int32_t *best_dist)
 {
+    oracle_grid grid;
+    grid_build(kf, &grid);
     const int n = kf->n;
     int32_t *ind = (int32_t *)malloc(sizeof(int32_t) * (n + 1));
     for (int i = 0; i < nq; ++i) {
         best_idx[i] = -1; best_dist[i] = 256;
         if (!q[i].valid) continue;
         const float u = q[i].u, v = q[i].v, ur = q[i].ur;
-        int nind = oracle_features_in_area(kf, u, v, q[i].radius, -1, -1, ind, n);  /* KeyFrame::GetFeaturesInArea */
+        int nind = features_in_area_grid(kf, &grid, u, v, q[i].radius, -1, -1, ind, n);  /* KeyFrame::GetFeaturesInArea */
         int bestDist = 256, bestIdx = -1;
         for (int c = 0; c < nind; ++c) {
             const int idx = ind[c];
@@ -1009,6 +1050,7 @@ void oracle_search_best_in_window(const oracle_frame *kf, const oracle_query *q,
         best_idx[i] = bestIdx; best_dist[i] = bestDist;
     }
     free(ind);
+    grid_free(&grid);
 }
 
 /* SearchByProjection(Frame&,const vector<MapPoint*>&,th), ORBmatcher.cc:45-129 */
@@ -1016,6 +1058,8 @@ int oracle_search_by_projection_points(const oracle_frame *f, const oracle_query
                                        const uint8_t *qdesc, int nq, const uint8_t *taken_in,
                                        int32_t *assign, float nnratio)
 {
+    oracle_grid grid;
+    grid_build(f, &grid);
     int nmatches = 0;
     const int n = f->n;
     uint8_t *taken = (uint8_t *)malloc(n + 1);
@@ -1024,7 +1068,7 @@ int oracle_search_by_projection_points(const oracle_frame *f, const oracle_query
     for (int iMP = 0; iMP < nq; ++iMP) {
         if (!q[iMP].valid) continue;
         const float r = q[iMP].radius;
-        int nind = oracle_features_in_area(f, q[iMP].u, q[iMP].v, r, q[iMP].min_level, q[iMP].max_level, ind, n);
+        int nind = features_in_area_grid(f, &grid, q[iMP].u, q[iMP].v, r, q[iMP].min_level, q[iMP].max_level, ind, n);
         if (nind == 0) continue;
         const uint8_t *dMP = qdesc + (size_t)iMP * 32;
         int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
@@ -1051,7 +1095,7 @@ int oracle_search_by_projection_points(const oracle_frame *f, const oracle_query
         }
     }
     free(taken); free(ind);
-    return nmatches;
+    grid_free(&grid); return nmatches;
 }
 
 /* ---- vocabulary-node guided searches ------------------------------------------------------

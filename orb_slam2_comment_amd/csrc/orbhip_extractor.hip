@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ 
                                                     PyrGeom G)
 {
     // one thread = kL0Q x 16 bytes of the padded destination row (uint4 stores).  Interior groups read their 16
-    // source bytes as five aligned dwords re-aligned with v_alignbyte_b32 (image rows have an odd stride);
-    // groups touching the REFLECT_101 frame or the row ends go byte by byte.
+    // source bytes with one byte-aligned 16-byte load (image rows have an odd stride; the hardware takes unaligned
+    // global loads); groups touching the REFLECT_101 frame or the row ends go byte by byte.
     const LevelGeom L = G.lv[0];
     const int quads = L.pitch >> 4, units = (quads + kL0Q - 1) / kL0Q;
     int bx, fr;
@@ -164,21 +164,15 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ 
     const int sy = reflect101(py - kEdge, L.h);
     const uint8_t *srow = src + (size_t)sy * stride;
     uint8_t *drow = dst + (size_t)py * L.pitch;
-    uint32_t out[kL0Q][4];
+    uint4 out[kL0Q];
 #pragma unroll
     for (int q = 0; q < kL0Q; ++q) {
         const int pq = min(pu * kL0Q + q, quads - 1);   // the tail repeats the last group (same bytes stored twice)
         const int x0 = pq * 16 - kPadL;
-        if (x0 >= 16 && x0 + 19 < L.w) {
-            const uint8_t *p = srow + x0;
-            const unsigned al = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(p - al);
-            const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
-            out[q][0] = __builtin_amdgcn_alignbyte(d1, d0, al);
-            out[q][1] = __builtin_amdgcn_alignbyte(d2, d1, al);
-            out[q][2] = __builtin_amdgcn_alignbyte(d3, d2, al);
-            out[q][3] = __builtin_amdgcn_alignbyte(d4, d3, al);
+        if (x0 >= 0 && x0 + 16 <= L.w) {
+            __builtin_memcpy(&out[q], srow + x0, 16);
         } else {
+            uint32_t o4[4];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 uint32_t acc = 0;
@@ -189,14 +183,15 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ 
                     if (x >= -kEdge && x < L.w + kEdge) v = srow[reflect101(x, L.w)];
                     acc |= v << (8 * k);
                 }
-                out[q][w] = acc;
+                o4[w] = acc;
             }
+            out[q] = make_uint4(o4[0], o4[1], o4[2], o4[3]);
         }
     }
 #pragma unroll
     for (int q = 0; q < kL0Q; ++q) {
         const int pq = min(pu * kL0Q + q, quads - 1);
-        *reinterpret_cast<uint4 *>(drow + pq * 16) = make_uint4(out[q][0], out[q][1], out[q][2], out[q][3]);
+        *reinterpret_cast<uint4 *>(drow + pq * 16) = out[q];
     }
 }
 
@@ -264,28 +259,21 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
     }
     uint32_t out[kPyrRows];
     if (hi - lo <= 6) {   // the 8-byte source window covers all four taps (scale factors <= 2.3)
-        const int base = lo & ~3, o = lo & 3;
-        uint32_t d[kPyrRows][6];
+        unsigned long long w0[kPyrRows], w1[kPyrRows];   // source bytes lo .. lo+7 of the two source rows (unaligned loads)
 #pragma unroll
         for (int r = 0; r < kPyrRows; ++r) {
             // rows < 4038 and pitch < 4200 fit the full-rate 24-bit multiplier (a 64-bit mad is quarter rate)
-            const uint32_t *p0 = reinterpret_cast<const uint32_t *>(sroi + (uint32_t)__mul24((int)yt[r].x, P.pitch) + base);
-            const uint32_t *p1 = reinterpret_cast<const uint32_t *>(sroi + (uint32_t)__mul24((int)yt[r].y, P.pitch) + base);
-            d[r][0] = p0[0]; d[r][1] = p0[1]; d[r][2] = p0[2];
-            d[r][3] = p1[0]; d[r][4] = p1[1]; d[r][5] = p1[2];
+            __builtin_memcpy(&w0[r], sroi + (uint32_t)__mul24((int)yt[r].x, P.pitch) + lo, 8);
+            __builtin_memcpy(&w1[r], sroi + (uint32_t)__mul24((int)yt[r].y, P.pitch) + lo, 8);
         }
         const int rel[4] = {sxk[0] - lo, sxk[1] - lo, sxk[2] - lo, sxk[3] - lo};
 #pragma unroll
         for (int r = 0; r < kPyrRows; ++r) {
-            const unsigned long long w0 = ((unsigned long long)__builtin_amdgcn_alignbyte(d[r][2], d[r][1], o) << 32) |
-                                          __builtin_amdgcn_alignbyte(d[r][1], d[r][0], o);   // source bytes lo .. lo+7
-            const unsigned long long w1 = ((unsigned long long)__builtin_amdgcn_alignbyte(d[r][5], d[r][4], o) << 32) |
-                                          __builtin_amdgcn_alignbyte(d[r][4], d[r][3], o);
             const int b0 = yt[r].z, b1 = yt[r].w;
             uint32_t acc = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t q0 = (uint32_t)(w0 >> (8 * rel[k])), q1 = (uint32_t)(w1 >> (8 * rel[k]));
+                const uint32_t q0 = (uint32_t)(w0[r] >> (8 * rel[k])), q1 = (uint32_t)(w1[r] >> (8 * rel[k]));
                 const uint32_t h0 = udot2(__builtin_amdgcn_perm(0u, q0, 0x0c010c00u), alv[k], 0);
                 const uint32_t h1 = udot2(__builtin_amdgcn_perm(0u, q1, 0x0c010c00u), alv[k], 0);
                 // b <= 2048 and h >> 4 < 2^15: the 24-bit multiplier is exact and full rate (v_mul_lo_u32 is quarter rate)
@@ -1459,26 +1447,36 @@ static int ensure_batch(orbhip_extractor *e, int batch)
     return ORBHIP_OK;
 }
 
+// `frame0`: first internal frame slot of this launch (the host path runs a batch as several chunks, each in its own
+// slots, so that every frame's pyramid stays resident for orbhip_pyramid_level / ComputeStereoMatches afterwards)
 static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int batch, int stride,
                            size_t frame_stride, orbhip_keypoint *d_kps, uint8_t *d_desc, int cap,
-                           int *d_n, int *d_status)
+                           int *d_n, int *d_status, int frame0 = 0)
 {
     const PyrGeom &G = e->G;
     hipStream_t s = e->stream;
+    // per-frame internal buffers of this launch
+    uint8_t *const b_pyr = e->d_pyr + (size_t)frame0 * G.frame_bytes, *const b_blur = e->d_blur + (size_t)frame0 * G.frame_bytes;
+    int *const b_cell_cnt = e->d_cell_cnt + (size_t)frame0 * std::max(G.ncells_total, 1);
+    uint32_t *const b_cell_kp = e->d_cell_kp + (size_t)frame0 * std::max(G.ncells_total, 1) * G.slot_cap;
+    uint32_t *const b_keys = e->d_keys + (size_t)frame0 * G.cand_cap_total;
+    unsigned short *const b_knode = e->d_knode + (size_t)frame0 * G.cand_cap_total;
+    uint32_t *const b_sel = e->d_sel + (size_t)frame0 * G.kp_cap_total;
+    int *const b_sel_cnt = e->d_sel_cnt + (size_t)frame0 * ORBHIP_MAX_LEVELS;
     const bool prof = e->profiling;
     hipEvent_t *ev = prof ? &e->ev[(size_t)(e->prof_calls % orbhip_extractor::kProfRing) * orbhip_extractor::kProfEv] : nullptr;
-    int *status = d_status ? d_status : e->d_status;
+    int *status = d_status ? d_status : e->d_status + frame0;
     hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
     if (prof) (void)hipEventRecord(ev[0], s);
     {
         const LevelGeom &L = G.lv[0];
         int n = (((L.pitch >> 4) + kL0Q - 1) / kL0Q) * L.prows;
         hipLaunchKernelGGL(k_pyr_level0, dim3((n + 255) / 256, batch), dim3(256), 0, s, d_images, stride,
-                           frame_stride, e->d_pyr, G);
+                           frame_stride, b_pyr, G);
         for (int l = 1; l < G.nlevels; ++l) {
             const LevelGeom &Ll = G.lv[l];
             int nl = (Ll.pitch >> 2) * ((Ll.prows + kPyrRows - 1) / kPyrRows);
-            hipLaunchKernelGGL(k_pyr_resize, dim3((nl + 255) / 256, batch), dim3(256), 0, s, e->d_pyr, G, l, e->d_tabs);
+            hipLaunchKernelGGL(k_pyr_resize, dim3((nl + 255) / 256, batch), dim3(256), 0, s, b_pyr, G, l, e->d_tabs);
         }
     }
     if (prof) (void)hipEventRecord(ev[1], s);
@@ -1492,9 +1490,9 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         if ((unsigned long long)G.ncells_total * G.ncells_total * (unsigned long long)batch >= (1ull << 32)) {
             set_error("batch too large for the FAST kernel's work mapping"); return ORBHIP_E_SIZE;
         }
-#define ORBHIP_FAST2(SWv) hipLaunchKernelGGL(k_fast_cells<SWv>, grid, dim3(64), lb, s, e->d_pyr, e->d_cells2, e->d_cell_cnt, e->d_cell_kp, P)
+#define ORBHIP_FAST2(SWv) hipLaunchKernelGGL(k_fast_cells<SWv>, grid, dim3(64), lb, s, b_pyr, e->d_cells2, b_cell_cnt, b_cell_kp, P)
         if (e->fast_variant == 2 && e->fast_lds.strideW == 11)   // stamped diagnostic build (tools/fast_ab.py)
-            hipLaunchKernelGGL((k_fast_cells<11, true>), grid, dim3(64), lb, s, e->d_pyr, e->d_cells2, e->d_cell_cnt, e->d_cell_kp, P);
+            hipLaunchKernelGGL((k_fast_cells<11, true>), grid, dim3(64), lb, s, b_pyr, e->d_cells2, b_cell_cnt, b_cell_kp, P);
         else switch (e->fast_lds.strideW) {
         case 11: ORBHIP_FAST2(11); break;
         case 13: ORBHIP_FAST2(13); break;
@@ -1506,22 +1504,22 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     }
     if (prof) (void)hipEventRecord(ev[2], s);
     if (e->octree_maxn == 512)
-        hipLaunchKernelGGL(k_octree<512>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
-                           e->d_keys, e->d_knode, e->d_sel, e->d_sel_cnt, status);
+        hipLaunchKernelGGL(k_octree<512>, dim3(G.nlevels, batch), dim3(256), 0, s, G, b_cell_cnt, b_cell_kp,
+                           b_keys, b_knode, b_sel, b_sel_cnt, status);
     else
-        hipLaunchKernelGGL(k_octree<2048>, dim3(G.nlevels, batch), dim3(256), 0, s, G, e->d_cell_cnt, e->d_cell_kp,
-                           e->d_keys, e->d_knode, e->d_sel, e->d_sel_cnt, status);
+        hipLaunchKernelGGL(k_octree<2048>, dim3(G.nlevels, batch), dim3(256), 0, s, G, b_cell_cnt, b_cell_kp,
+                           b_keys, b_knode, b_sel, b_sel_cnt, status);
     if (prof) (void)hipEventRecord(ev[3], s);
     // The blur only needs the pyramid.  Forking it onto a second stream beside FAST/octree was measured: it buys
     // nothing once two pipelines (handles) run concurrently and makes throughput depend on how the runtime maps
     // streams to hardware queues (122 k vs 136 k frames/s run to run), so it stays in order on this stream.
-    hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, e->d_pyr, e->d_blur, G,
+    hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, b_pyr, b_blur, G,
                        e->d_tiles, e->blurw);
     if (prof) (void)hipEventRecord(ev[4], s);
-    hipLaunchKernelGGL(k_orient_describe, dim3((G.kp_cap_total + 3) / 4, batch), dim3(256), 0, s, e->d_pyr, e->d_blur,
-                       G, e->d_sel, e->d_sel_cnt, e->d_disc, e->d_pattern, d_kps, d_desc, cap, d_n, status);
+    hipLaunchKernelGGL(k_orient_describe, dim3((G.kp_cap_total + 3) / 4, batch), dim3(256), 0, s, b_pyr, b_blur,
+                       G, b_sel, b_sel_cnt, e->d_disc, e->d_pattern, d_kps, d_desc, cap, d_n, status);
     if (prof) { (void)hipEventRecord(ev[5], s); e->prof_calls++; }
-    e->last_batch = batch;
+    e->last_batch = frame0 + batch;
     ORBHIP_HIP_CHECK(hipGetLastError());
     return ORBHIP_OK;
 }
@@ -1612,6 +1610,9 @@ void orbhip_extractor_destroy(orbhip_extractor *e)
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     for (hipEvent_t v : e->ev) (void)hipEventDestroy(v);
+    for (hipEvent_t v : e->ev_chunk) (void)hipEventDestroy(v);
+    if (e->s_in) (void)hipStreamDestroy(e->s_in);
+    if (e->s_out) (void)hipStreamDestroy(e->s_out);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -1718,17 +1719,76 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
         e->h_out_bytes = out_bytes;
     }
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));   // the staging buffer of the previous call is free
-    for (int b = 0; b < batch; ++b) {
-        const uint8_t *src = images + b * frame_stride;
-        uint8_t *dst = e->h_in + (size_t)b * rows * cols;
-        if (stride == cols) memcpy(dst, src, (size_t)rows * cols);
-        else for (int r = 0; r < rows; ++r) memcpy(dst + (size_t)r * cols, src + (size_t)r * stride, cols);
-    }
     rc = ensure_batch(e, batch);
     if (rc) return rc;
     int *h_n = reinterpret_cast<int *>(e->h_out), *h_st = h_n + batch;
     orbhip_keypoint *h_kp = reinterpret_cast<orbhip_keypoint *>(h_st + batch);
     uint8_t *h_desc = reinterpret_cast<uint8_t *>(h_kp + (size_t)batch * cap);
+    auto stage_in = [&](int b0, int nb) {   // caller's frames -> pinned staging (row copies on the CPU)
+        for (int b = b0; b < b0 + nb; ++b) {
+            const uint8_t *src = images + b * frame_stride;
+            uint8_t *dst = e->h_in + (size_t)b * rows * cols;
+            if (stride == cols) memcpy(dst, src, (size_t)rows * cols);
+            else for (int r = 0; r < rows; ++r) memcpy(dst + (size_t)r * cols, src + (size_t)r * stride, cols);
+        }
+    };
+    auto deliver = [&](int b0, int nb, int &bad) {   // pinned staging -> caller's buffers; truncated frames are still delivered
+        for (int b = b0; b < b0 + nb; ++b) {
+            n[b] = std::min(h_n[b], cap);
+            if (h_st[b] != 0 && bad < 0) bad = b;
+            if (n[b] > 0) {
+                memcpy(kps + (size_t)b * cap, h_kp + (size_t)b * cap, (size_t)n[b] * sizeof(orbhip_keypoint));
+                memcpy(desc + (size_t)b * cap * 32, h_desc + (size_t)b * cap * 32, (size_t)n[b] * 32);
+            }
+        }
+    };
+    // Large batches run as a software pipeline of 16-frame chunks on three streams: while the kernels of chunk k run,
+    // chunk k+1 is copied into pinned memory by the CPU and over PCIe by the DMA engine, and the results of chunk k-1
+    // travel back and are handed to the caller.  What a Tracking thread sees is still one synchronous call.
+    constexpr int kChunk = 16;
+    static const bool no_pipe = getenv("ORBHIP_NO_PIPELINE") != nullptr;
+    if (batch >= 2 * kChunk && !e->profiling && !no_pipe) {
+        if (!e->s_in) {
+            ORBHIP_HIP_CHECK(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+            ORBHIP_HIP_CHECK(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
+        }
+        const int nchunks = (batch + kChunk - 1) / kChunk;
+        while ((int)e->ev_chunk.size() < 3 * nchunks) {
+            hipEvent_t ev;
+            ORBHIP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e->ev_chunk.push_back(ev);
+        }
+        const size_t fbytes = (size_t)rows * cols;
+        for (int c = 0; c < nchunks; ++c) {
+            const int b0 = c * kChunk, nb = std::min(kChunk, batch - b0);
+            hipEvent_t ev_in = e->ev_chunk[3 * c], ev_k = e->ev_chunk[3 * c + 1], ev_out = e->ev_chunk[3 * c + 2];
+            stage_in(b0, nb);
+            ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img + b0 * fbytes, e->h_in + b0 * fbytes, nb * fbytes, hipMemcpyHostToDevice, e->s_in));
+            ORBHIP_HIP_CHECK(hipEventRecord(ev_in, e->s_in));
+            ORBHIP_HIP_CHECK(hipStreamWaitEvent(e->stream, ev_in, 0));
+            rc = launch_pipeline(e, e->d_img + b0 * fbytes, nb, cols, fbytes, e->d_okp + (size_t)b0 * cap, e->d_odesc + (size_t)b0 * cap * 32,
+                                 cap, e->d_on + b0, nullptr, b0);
+            if (rc) { (void)hipDeviceSynchronize(); return rc; }
+            ORBHIP_HIP_CHECK(hipEventRecord(ev_k, e->stream));
+            ORBHIP_HIP_CHECK(hipStreamWaitEvent(e->s_out, ev_k, 0));
+            ORBHIP_HIP_CHECK(hipMemcpyAsync(h_n + b0, e->d_on + b0, nb * sizeof(int), hipMemcpyDeviceToHost, e->s_out));
+            ORBHIP_HIP_CHECK(hipMemcpyAsync(h_st + b0, e->d_status + b0, nb * sizeof(int), hipMemcpyDeviceToHost, e->s_out));
+            ORBHIP_HIP_CHECK(hipMemcpyAsync(h_kp + (size_t)b0 * cap, e->d_okp + (size_t)b0 * cap, (size_t)nb * cap * sizeof(orbhip_keypoint),
+                                            hipMemcpyDeviceToHost, e->s_out));
+            ORBHIP_HIP_CHECK(hipMemcpyAsync(h_desc + (size_t)b0 * cap * 32, e->d_odesc + (size_t)b0 * cap * 32, (size_t)nb * cap * 32,
+                                            hipMemcpyDeviceToHost, e->s_out));
+            ORBHIP_HIP_CHECK(hipEventRecord(ev_out, e->s_out));
+        }
+        int bad = -1;
+        for (int c = 0; c < nchunks; ++c) {
+            ORBHIP_HIP_CHECK(hipEventSynchronize(e->ev_chunk[3 * c + 2]));
+            deliver(c * kChunk, std::min(kChunk, batch - c * kChunk), bad);
+        }
+        ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+        if (bad >= 0) { set_error("frame %d: capacity exceeded (cap %d); outputs are truncated", bad, cap); return ORBHIP_E_CAPACITY; }
+        return ORBHIP_OK;
+    }
+    stage_in(0, batch);
     auto enqueue = [&]() -> int {
         ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img, e->h_in, img_bytes, hipMemcpyHostToDevice, e->stream));
         int r = launch_pipeline(e, e->d_img, batch, cols, (size_t)rows * cols, e->d_okp, e->d_odesc, cap, e->d_on, nullptr);
@@ -1766,14 +1826,11 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
         if (rc) return rc;
     }
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
-    for (int b = 0; b < batch; ++b) {
-        n[b] = h_n[b];
-        if (h_st[b] != 0) { set_error("frame %d: capacity exceeded (cap %d)", b, cap); return ORBHIP_E_CAPACITY; }
-        if (n[b] > 0) {
-            memcpy(kps + (size_t)b * cap, h_kp + (size_t)b * cap, (size_t)n[b] * sizeof(orbhip_keypoint));
-            memcpy(desc + (size_t)b * cap * 32, h_desc + (size_t)b * cap * 32, (size_t)n[b] * 32);
-        }
-    }
+    // every frame's (possibly truncated) result is delivered before a capacity error is reported: n[] and the first
+    // n[b] <= cap keypoints / descriptors of every frame are valid either way
+    int bad = -1;
+    deliver(0, batch, bad);
+    if (bad >= 0) { set_error("frame %d: capacity exceeded (cap %d); outputs are truncated", bad, cap); return ORBHIP_E_CAPACITY; }
     return ORBHIP_OK;
 }
 

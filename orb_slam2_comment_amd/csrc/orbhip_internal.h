@@ -87,6 +87,9 @@ struct orbhip_extractor {
     // hipGraphLaunch -- a single frame is launch-bound, not GPU-bound
     hipGraphExec_t graph_exec = nullptr;
     int graph_batch = 0, graph_cap = 0;
+    // chunked host path: copy-in / copy-out streams and per-chunk events (created on first use)
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<hipEvent_t> ev_chunk;
     // pinned host staging (pageable 2-D copies are an order of magnitude slower than one pinned DMA)
     uint8_t *h_in = nullptr; size_t h_in_bytes = 0;
     uint8_t *h_out = nullptr; size_t h_out_bytes = 0;

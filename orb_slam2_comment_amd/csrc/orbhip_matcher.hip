@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_bow_groups(const NodeGroup *__restrict_
             int bin = 0xff;
             if (res >= 0 && check_ori) {
                 bin = rot_bin(qangle[qi], tkeys[res].angle);
-                atomicAdd(&hist[bin], 1);
+                if (bin >= 0) atomicAdd(&hist[bin], 1); else bin = 0xff;
             }
             bin_out[qi] = (uint8_t)bin;
         }
@@ -408,8 +408,7 @@ __global__ __launch_bounds__(1024) void k_bow_pairs(BowSide Q, BowSide T, int ca
                     S.mout[qi] = idx2;
                     if (check_ori) {
                         const int b = rot_bin(qk[idx1].angle, tk[idx2].angle);
-                        atomicAdd(&S.hist[b], 1);
-                        S.bin[qi] = (unsigned char)b;
+                        if (b >= 0) { atomicAdd(&S.hist[b], 1); S.bin[qi] = (unsigned char)b; }
                     }
                 }
             }
@@ -612,7 +611,9 @@ __device__ __forceinline__ int rot_bin(float a1, float a2)
     if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
     int bin = (int)roundf(__fmul_rn(rot, factor));
     if (bin == HISTO_LENGTH) bin = 0;
-    return bin;
+    // keypoint angles are caller data: outside [0, 360) (or NaN) the reference trips its assert(bin>=0 && bin<HISTO_LENGTH);
+    // here such a match simply takes no part in the rotation histogram (-1) instead of writing outside it
+    return (bin >= 0 && bin < HISTO_LENGTH) ? bin : -1;
 }
 
 // First / second usable candidate of a query.  `usable(idx, dist)` is evaluated by every lane.
@@ -729,9 +730,11 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
                     S.block[bestIdx] = (unsigned short)S.q_obs[i];
                     if (check_ori) {
                         int bin = rot_bin(S.q_angle[i], S.t_angle[bestIdx]);
-                        S.hist[bin]++;
-                        S.evbin[i] = (unsigned char)bin;
-                        S.evidx[i] = (unsigned short)bestIdx;
+                        if (bin >= 0) {
+                            S.hist[bin]++;
+                            S.evbin[i] = (unsigned char)bin;
+                            S.evidx[i] = (unsigned short)bestIdx;
+                        }
                     }
                 }
                 nmatches++;
@@ -763,8 +766,7 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
                         S.block[bestIdx] = (unsigned short)bestDist;
                         if (check_ori) {
                             int bin = rot_bin(S.q_angle[i], S.t_angle[bestIdx]);
-                            S.hist[bin]++;
-                            S.evbin[i] = (unsigned char)bin;
+                            if (bin >= 0) { S.hist[bin]++; S.evbin[i] = (unsigned char)bin; }
                         }
                     }
                     nmatches++;
@@ -808,24 +810,42 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
 // so it can be found by fixed-point iteration: every round all queries re-pick in parallel against the
 // owners (smallest accepted observed query per slot) of the previous round; query i is final once all
 // j < i are, so at most nq+1 rounds are needed and typically 3-5.  One workgroup, state in LDS.
-struct ResolveParShared {
-    int owner[2][kResolveMax];           // smallest accepted+observed query that picks the slot (ping-pong)
-    short choice[kResolveMax];           // slot picked by query i, -1 if none accepted
-    float t_angle[kResolveMax], q_angle[kResolveMax];
-    unsigned char t_oct[kResolveMax], q_obs[kResolveMax], taken[kResolveMax], evbin[kResolveMax];
-    int hist[HISTO_LENGTH];
-    int changed, nacc, ncull;
+// State of the parallel resolve.  Up to kResolveMax train keypoints and queries it lives in LDS (GS = false); beyond
+// that the same arrays are carved out of an HBM workspace (GS = true: same code, global loads / atomics).
+struct ResolveParState {
+    int *owner[2];                       // smallest accepted+observed query that picks the slot (ping-pong)
+    int *choice;                         // slot picked by query i, -1 if none accepted
+    float *t_angle, *q_angle;
+    unsigned char *t_oct, *q_obs, *taken, *evbin;
+    int *hist;                           // HISTO_LENGTH bins
+    int *vars;                           // changed, nacc, ncull
 };
+__host__ __device__ inline size_t resolve_par_bytes(size_t n, size_t nq)
+{
+    n = (n + 3) & ~(size_t)3; nq = (nq + 3) & ~(size_t)3;
+    return (2 * n + nq + n + nq) * 4 + 2 * n + 2 * nq + (HISTO_LENGTH + 2 + 4) * 4;
+}
+__device__ __forceinline__ void resolve_par_carve(ResolveParState &S, unsigned char *base, size_t n, size_t nq)
+{
+    n = (n + 3) & ~(size_t)3; nq = (nq + 3) & ~(size_t)3;
+    int *p = reinterpret_cast<int *>(base);
+    S.owner[0] = p; p += n; S.owner[1] = p; p += n; S.choice = p; p += nq;
+    S.t_angle = reinterpret_cast<float *>(p); p += n; S.q_angle = reinterpret_cast<float *>(p); p += nq;
+    S.hist = p; p += HISTO_LENGTH + 2; S.vars = p; p += 4;
+    unsigned char *c = reinterpret_cast<unsigned char *>(p);
+    S.t_oct = c; c += n; S.taken = c; c += n; S.q_obs = c; c += nq; S.evbin = c;
+}
 
+template <bool GS>
 __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, const orbhip_query *__restrict__ q, int nq,
                                                       const unsigned long long *__restrict__ cand,
                                                       const int *__restrict__ cnt, int stride,
                                                       const uint8_t *__restrict__ taken_in, float nnratio,
                                                       int check_ori, int *__restrict__ out, int *__restrict__ out_n, Batch B,
-                                                      int th_accept, int all_block)
+                                                      int th_accept, int all_block, unsigned char *__restrict__ gstate,
+                                                      size_t gstate_stride)
 {
     extern __shared__ unsigned char resolve_lds[];
-    ResolveParShared &S = *reinterpret_cast<ResolveParShared *>(resolve_lds);
     const int tid = threadIdx.x, T = blockDim.x;
     {
         const int pair = blockIdx.x;
@@ -839,6 +859,9 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
         if (B.nq_dev) nq = min(B.nq_dev[pair], B.qcap);
     }
     const int n = F.n;
+    ResolveParState S;
+    if (GS) resolve_par_carve(S, gstate + (size_t)blockIdx.x * gstate_stride, (size_t)n, (size_t)nq);
+    else resolve_par_carve(S, resolve_lds, kResolveMax, kResolveMax);
     for (int i = tid; i < n; i += T) {
         S.owner[0][i] = INT_MAX;
         S.taken[i] = (unsigned char)(taken_in ? taken_in[i] != 0 : 0);
@@ -852,11 +875,11 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
         S.evbin[i] = 0xff;
     }
     if (tid < HISTO_LENGTH) S.hist[tid] = 0;
-    if (tid == 0) { S.nacc = 0; S.ncull = 0; }
+    if (tid == 0) { S.vars[1] = 0; S.vars[2] = 0; }
     __syncthreads();
     int cur = 0;
     for (int round = 0; round <= nq + 1; ++round) {
-        if (tid == 0) S.changed = 0;
+        if (tid == 0) S.vars[0] = 0;
         for (int c = tid; c < n; c += T) S.owner[cur ^ 1][c] = INT_MAX;
         __syncthreads();
         for (int i = tid; i < nq; i += T) {
@@ -893,12 +916,12 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                     if (acc) newc = bestIdx;
                 }
             }
-            if (newc != S.choice[i]) { S.choice[i] = (short)newc; S.changed = 1; }
+            if (newc != S.choice[i]) { S.choice[i] = newc; S.vars[0] = 1; }
             if (newc >= 0 && S.q_obs[i]) atomicMin(&S.owner[cur ^ 1][newc], i);
         }
         __syncthreads();
         cur ^= 1;
-        const int changed = S.changed;
+        const int changed = S.vars[0];
         __syncthreads();
         if (!changed) break;
     }
@@ -915,11 +938,13 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
         atomicMax(&assign[c], i);
         if (ori) {
             const int bin = rot_bin(S.q_angle[i], S.t_angle[c]);
-            atomicAdd(&S.hist[bin], 1);
-            S.evbin[i] = (unsigned char)bin;
+            if (bin >= 0) {
+                atomicAdd(&S.hist[bin], 1);
+                S.evbin[i] = (unsigned char)bin;
+            }
         }
     }
-    if (acc_local) atomicAdd(&S.nacc, acc_local);
+    if (acc_local) atomicAdd(&S.vars[1], acc_local);
     __syncthreads();
     if (ori) {
         int ind1, ind2, ind3;
@@ -932,12 +957,12 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                 ++cull;
             }
         }
-        if (cull) atomicAdd(&S.ncull, cull);
+        if (cull) atomicAdd(&S.vars[2], cull);
         __syncthreads();
     }
     if (mode == 4) for (int i = tid; i < nq; i += T) out[i] = S.choice[i];   // per query, no slot exclusivity
     else for (int c = tid; c < n; c += T) out[c] = assign[c];
-    if (tid == 0) *out_n = S.nacc - S.ncull;
+    if (tid == 0) *out_n = S.vars[1] - S.vars[2];
 }
 
 // ---- DescriptorDistance, batched (ORBmatcher.cc:1647-1663) --------------------------------
@@ -1569,8 +1594,8 @@ struct orbhip_matcher {
     hipStream_t stream = nullptr;       // stream every launch goes to
     hipStream_t own_stream = nullptr;   // created with the handle
     // grow-only device scratch
-    void *buf[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t cap[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void *buf[16] = {};
+    size_t cap[16] = {};
     bool lds_attr_set = false, bow_attr_set = false;
     // pinned host staging: all inputs of a call travel in one DMA, all outputs in one
     uint8_t *h_stage = nullptr; size_t h_stage_bytes = 0;
@@ -1605,7 +1630,7 @@ static int scratch(orbhip_matcher *m, int slot, size_t bytes, void **out)
     return ORBHIP_OK;
 }
 
-enum { S_KEYS = 0, S_DESC, S_UR, S_ORD, S_Q, S_QDESC, S_CAND, S_CNT, S_TAKEN, S_OUT, S_QKEYS, S_MISC };
+enum { S_KEYS = 0, S_DESC, S_UR, S_ORD, S_Q, S_QDESC, S_CAND, S_CNT, S_TAKEN, S_OUT, S_QKEYS, S_MISC, S_STATE, S_NSLOTS };
 
 static int stage_begin(orbhip_matcher *m, size_t total, Stage *st)
 {
@@ -1645,50 +1670,97 @@ static int ensure_resolve_attr(orbhip_matcher *m)
     if (!m->lds_attr_set) {   // > 64 KB of dynamic LDS needs the opt-in attribute (per device)
         ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)sizeof(ResolveShared)));
-        ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_par), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)sizeof(ResolveParShared)));
+        ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_par<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)resolve_par_bytes(kResolveMax, kResolveMax)));
         m->lds_attr_set = true;
     }
     return ORBHIP_OK;
 }
 
-// shared driver of the three windowed searches
+// launch of the parallel resolve: LDS state up to kResolveMax train keypoints / queries, HBM state beyond
+static int launch_resolve_par(orbhip_matcher *m, int pairs, int mode, const DevFrame &D, const orbhip_query *d_q, int nq,
+                              int n_train, const unsigned long long *d_cand, const int *d_cnt, int stride,
+                              const uint8_t *d_taken, float nnratio, int check_ori, int *d_out, int *d_out_n, const Batch &B,
+                              int th_accept, int all_block)
+{
+    if (n_train <= kResolveMax && nq <= kResolveMax) {
+        hipLaunchKernelGGL(k_resolve_par<false>, dim3(pairs), dim3(1024), resolve_par_bytes(kResolveMax, kResolveMax), m->stream,
+                           mode, D, d_q, nq, d_cand, d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out_n, B, th_accept,
+                           all_block, (unsigned char *)nullptr, (size_t)0);
+    } else {
+        const size_t per = al256(resolve_par_bytes((size_t)n_train, (size_t)nq));
+        void *p;
+        int rc = scratch(m, S_STATE, per * (size_t)pairs, &p);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_resolve_par<true>, dim3(pairs), dim3(1024), 0, m->stream, mode, D, d_q, nq, d_cand, d_cnt, stride,
+                           d_taken, nnratio, check_ori, d_out, d_out_n, B, th_accept, all_block, (unsigned char *)p, per);
+    }
+    return ORBHIP_OK;
+}
+
+// shared driver of the three windowed searches.  Modes 0 / 1 (the SearchByProjection family): queries with valid == 0
+// (no map point, not in view, ...) never reach the device -- local maps and loop-closing point sets are mostly that --
+// and there is no size limit (beyond kResolveMax the resolve state moves from LDS to HBM).  Mode 2
+// (SearchForInitialization) replays the match stealing on one wavefront with its state in LDS: <= kResolveMax.
 static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *train, const orbhip_query *q,
                       const uint8_t *qdesc, const orbhip_keypoint *qkeys, int nq, const uint8_t *taken,
                       float nnratio, int check_ori, int32_t *out, int nout, int *nmatches, int th_accept = TH_HIGH,
                       int all_block = 0, int use_ur = 1)
 {
     ORBHIP_HIP_CHECK(hipSetDevice(m->device));
-    if (train->n > kResolveMax || nq > kResolveMax) {
-        set_error("matcher: %d train / %d query keypoints exceed the LDS-resident limit %d", train->n, nq, kResolveMax);
+    if (mode == 2 && (train->n > kResolveMax || nq > kResolveMax)) {
+        set_error("SearchForInitialization: %d / %d keypoints exceed the LDS-resident limit %d", train->n, nq, kResolveMax);
         return ORBHIP_E_CAPACITY;
     }
+    if (train->n >= (1 << 20)) { set_error("matcher: too many train keypoints"); return ORBHIP_E_CAPACITY; }
     for (int i = 0; i < nout; ++i) out[i] = -1;
     *nmatches = 0;
     if (nq == 0 || train->n == 0) return ORBHIP_OK;
+    // stable compaction of the valid queries (order = the reference's loop order)
+    static thread_local std::vector<int> vidx;
+    vidx.clear();
+    if (mode != 2) {
+        for (int i = 0; i < nq; ++i) if (q[i].valid) vidx.push_back(i);
+        if (vidx.empty()) return ORBHIP_OK;
+    }
+    const bool compact = mode != 2 && (int)vidx.size() < nq;
+    const int nqv = compact ? (int)vidx.size() : nq;
     const size_t n = (size_t)train->n;
     Stage st;
     int rc;
     if ((rc = stage_begin(m, al256(n * sizeof(orbhip_keypoint)) + al256(n * 32) + al256(n * 4) + al256(n) +
-                                 al256((size_t)nq * sizeof(orbhip_query)) + al256((size_t)nq * 32) +
-                                 al256((size_t)nq * sizeof(orbhip_keypoint)), &st))) return rc;
+                                 al256((size_t)nqv * sizeof(orbhip_query)) + al256((size_t)nqv * 32) +
+                                 al256((size_t)nqv * sizeof(orbhip_keypoint)), &st))) return rc;
     DevFrame D;
     D.n = train->n; D.min_x = train->min_x; D.min_y = train->min_y; D.inv_w = train->grid_inv_w; D.inv_h = train->grid_inv_h;
     D.keys = (const orbhip_keypoint *)st.put(train->keys, n * sizeof(orbhip_keypoint));
     D.desc = (const uint8_t *)st.put(train->desc, n * 32);
     D.u_right = train->u_right ? (const float *)st.put(train->u_right, n * sizeof(float)) : nullptr;
     const uint8_t *d_taken = taken ? (const uint8_t *)st.put(taken, n) : nullptr;
-    const orbhip_query *d_q = (const orbhip_query *)st.put(q, (size_t)nq * sizeof(orbhip_query));
-    const uint8_t *d_qdesc = (const uint8_t *)st.put(qdesc, (size_t)nq * 32);
+    const orbhip_query *d_q;
+    const uint8_t *d_qdesc;
+    if (compact) {
+        orbhip_query *hq = reinterpret_cast<orbhip_query *>(st.h + st.off);
+        d_q = (const orbhip_query *)st.put(nullptr, 0);
+        for (int k = 0; k < nqv; ++k) hq[k] = q[vidx[k]];
+        st.off += al256((size_t)nqv * sizeof(orbhip_query));
+        uint8_t *hd = st.h + st.off;
+        d_qdesc = (const uint8_t *)st.put(nullptr, 0);
+        for (int k = 0; k < nqv; ++k) memcpy(hd + (size_t)k * 32, qdesc + (size_t)vidx[k] * 32, 32);
+        st.off += al256((size_t)nqv * 32);
+    } else {
+        d_q = (const orbhip_query *)st.put(q, (size_t)nq * sizeof(orbhip_query));
+        d_qdesc = (const uint8_t *)st.put(qdesc, (size_t)nq * 32);
+    }
     const orbhip_keypoint *d_qkeys = qkeys ? (const orbhip_keypoint *)st.put(qkeys, (size_t)nq * sizeof(orbhip_keypoint)) : nullptr;
     if ((rc = stage_commit(m, &st))) return rc;
     void *p;
     if ((rc = scratch(m, S_ORD, n * sizeof(uint32_t), &p))) return rc;
     uint32_t *d_ord = (uint32_t *)p;
     const int stride = (train->n + 1) & ~1;
-    if ((rc = scratch(m, S_CAND, (size_t)nq * stride * sizeof(unsigned long long), &p))) return rc;
+    if ((rc = scratch(m, S_CAND, (size_t)nqv * stride * sizeof(unsigned long long), &p))) return rc;
     unsigned long long *d_cand = (unsigned long long *)p;
-    if ((rc = scratch(m, S_CNT, (size_t)nq * sizeof(int), &p))) return rc;
+    if ((rc = scratch(m, S_CNT, (size_t)nqv * sizeof(int), &p))) return rc;
     int *d_cnt = (int *)p;
     if ((rc = scratch(m, S_OUT, (size_t)(nout + 1) * sizeof(int), &p))) return rc;
     int *d_out = (int *)p;
@@ -1696,19 +1768,21 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
     if ((rc = out_buffer(m, (size_t)(nout + 1) * sizeof(int), &h_out))) return rc;
     const Batch one = {nullptr, nullptr, 0, 0};
     hipLaunchKernelGGL(k_grid_order, dim3((train->n + 255) / 256), dim3(256), 0, m->stream, D, d_ord, one);
-    hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_ord, d_q, d_qdesc, nq, d_cand,
+    hipLaunchKernelGGL(k_window_search, dim3((nqv + 3) / 4), dim3(256), 0, m->stream, D, d_ord, d_q, d_qdesc, nqv, d_cand,
                        d_cnt, stride, mode != 2 && use_ur, one);
     if ((rc = ensure_resolve_attr(m))) return rc;
     if (mode == 2)   // SearchForInitialization: match stealing depends on the running minimum distance -> serial replay
         hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(ResolveShared), m->stream, mode, D, d_qkeys, d_q, nq, d_cand,
                            d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout, one);
-    else
-        hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), sizeof(ResolveParShared), m->stream, mode, D, d_q, nq, d_cand,
-                           d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout, one, th_accept, all_block);
+    else if ((rc = launch_resolve_par(m, 1, mode, D, d_q, nqv, train->n, d_cand, d_cnt, stride, d_taken, nnratio, check_ori, d_out,
+                                      d_out + nout, one, th_accept, all_block)))
+        return rc;
     ORBHIP_HIP_CHECK(hipGetLastError());
     ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)(nout + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
     memcpy(out, h_out, (size_t)nout * sizeof(int));
+    if (compact)   // slots hold indices into the compacted query list: map them back
+        for (int i = 0; i < nout; ++i) if (out[i] >= 0) out[i] = vidx[out[i]];
     *nmatches = reinterpret_cast<const int *>(h_out)[nout];
     return ORBHIP_OK;
 }
@@ -1881,8 +1955,9 @@ static int run_tri(orbhip_matcher *m, const TriParams *tri, const orbhip_frame_v
     if ((rc = ensure_resolve_attr(m))) return rc;
     hipLaunchKernelGGL(k_tri_search, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_tnode, d_mask, d_q, d_qdesc, nq,
                        d_cand, d_cnt, stride, *tri);
-    hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), sizeof(ResolveParShared), m->stream, 4, D, d_q, nq, d_cand, d_cnt,
-                       stride, (const uint8_t *)nullptr, 0.f, check_ori, d_out, d_out + nq, one, TH_LOW, 0);
+    if ((rc = launch_resolve_par(m, 1, 4, D, d_q, nq, f2->n, d_cand, d_cnt, stride, (const uint8_t *)nullptr, 0.f, check_ori, d_out,
+                                 d_out + nq, one, TH_LOW, 0)))
+        return rc;
     ORBHIP_HIP_CHECK(hipGetLastError());
     ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)(nq + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -1920,7 +1995,7 @@ void orbhip_matcher_destroy(orbhip_matcher *m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    for (int i = 0; i < 12; ++i) (void)hipFree(m->buf[i]);
+    for (int i = 0; i < S_NSLOTS; ++i) (void)hipFree(m->buf[i]);
     if (m->h_stage) (void)hipHostFree(m->h_stage);
     if (m->h_out) (void)hipHostFree(m->h_out);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
@@ -2314,10 +2389,6 @@ static int search_device(orbhip_matcher *m, int mode, int pairs, const void *d_k
 {
     if (!m || pairs <= 0 || !d_kps || !d_desc || !d_n || !d_q || !d_qdesc || !d_nq || !d_assign || !d_nmatches || cap <= 0 || qcap <= 0)
         return ORBHIP_E_ARG;
-    if (cap > kResolveMax || qcap > kResolveMax) {
-        set_error("matcher: cap %d / qcap %d exceed the LDS-resident limit %d", cap, qcap, kResolveMax);
-        return ORBHIP_E_CAPACITY;
-    }
     ORBHIP_HIP_CHECK(hipSetDevice(m->device));
     int rc;
     void *p;
@@ -2336,9 +2407,9 @@ static int search_device(orbhip_matcher *m, int mode, int pairs, const void *d_k
     hipLaunchKernelGGL(k_grid_order, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, D, d_ord, B);
     hipLaunchKernelGGL(k_window_search, dim3((qcap + 3) / 4, pairs), dim3(256), 0, m->stream, D, d_ord, (const orbhip_query *)d_q,
                        (const uint8_t *)d_qdesc, qcap, d_cand, d_cnt, stride, 1, B);
-    hipLaunchKernelGGL(k_resolve_par, dim3(pairs), dim3(1024), sizeof(ResolveParShared), m->stream, mode, D,
-                       (const orbhip_query *)d_q, qcap, d_cand, d_cnt, stride, (const uint8_t *)d_taken, nnratio, check_ori,
-                       (int *)d_assign, (int *)d_nmatches, B, TH_HIGH, 0);
+    if ((rc = launch_resolve_par(m, pairs, mode, D, (const orbhip_query *)d_q, qcap, cap, d_cand, d_cnt, stride,
+                                 (const uint8_t *)d_taken, nnratio, check_ori, (int *)d_assign, (int *)d_nmatches, B, TH_HIGH, 0)))
+        return rc;
     ORBHIP_HIP_CHECK(hipGetLastError());
     return ORBHIP_OK;
 }

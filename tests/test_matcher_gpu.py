@@ -279,16 +279,66 @@ def test_device_batched_search_by_projection_equals_host_api(env):
             assert hn > 100
 
 
-def test_matcher_capacity_limit_is_an_error_not_garbage(env):
-    """More than 4096 keypoints per frame exceeds the LDS-resident resolve state: explicit E_CAPACITY."""
+def _big_frame(pkg, O, n, seed, W=1400, H=1000):
+    """n keypoints spread over a large image with descriptors in loose clusters (so that windows hold real candidates)."""
+    rng = np.random.default_rng(seed)
+    k = np.zeros(n, pkg.KP_DTYPE)
+    k["x"] = rng.uniform(20, W - 20, n).astype(np.float32)
+    k["y"] = rng.uniform(20, H - 20, n).astype(np.float32)
+    k["octave"] = rng.integers(0, 8, n)
+    k["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    proto = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    d = proto[rng.integers(0, 40, n)] ^ (rng.random((n, 32)) < 0.02).astype(np.uint8) * rng.integers(1, 256, (n, 32), dtype=np.uint8)
+    sf = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))])).astype(np.float32)
+    keep = []
+    gv = pkg.FrameView(k, d, sf, (0, 0, W, H))
+    ov = O.make_frame(k, d, None, (0, 0, W, H), sf, keep)
+    return k, d, sf, gv, ov, keep, rng
+
+
+@pytest.mark.parametrize("n_train,nq,valid_frac", [(1500, 8000, 0.2), (1500, 6000, 0.95), (5000, 3000, 0.9), (4500, 5200, 1.0)])
+def test_projection_searches_have_no_size_limit(env, n_train, nq, valid_frac):
+    """Local maps (Tracking::SearchLocalPoints) and loop-closing point sets exceed 4096 entries, most of them not in
+    view: invalid queries are dropped on the host, and beyond 4096 train keypoints / valid queries the resolve state
+    moves from LDS to HBM.  Same results as the oracle in every regime (reference: no limit)."""
+    pkg, M, O = env
+    k, d, sf, gv, ov, keep, rng = _big_frame(pkg, O, n_train, n_train + nq)
+    q = np.zeros(nq, pkg.QUERY_DTYPE)
+    src = rng.integers(0, n_train, nq)
+    q["valid"] = rng.random(nq) < valid_frac
+    q["u"] = k["x"][src] + rng.normal(0, 3, nq).astype(np.float32)
+    q["v"] = k["y"][src] + rng.normal(0, 3, nq).astype(np.float32)
+    q["radius"] = rng.uniform(8, 25, nq).astype(np.float32)
+    q["min_level"] = k["octave"][src] - 1
+    q["max_level"] = k["octave"][src] + 1
+    q["angle"] = (k["angle"][src] + rng.normal(0, 4, nq)).astype(np.float32) % np.float32(360)
+    q["observed"] = rng.random(nq) < 0.7
+    qd = d[src] ^ (rng.random((nq, 32)) < 0.03).astype(np.uint8) * rng.integers(1, 256, (nq, 32), dtype=np.uint8)
+    taken = (rng.random(n_train) < 0.05).astype(np.uint8)
+    m = pkg.ORBmatcher(0.8, True)
+    n, assign = m.SearchByProjectionFrame(gv, q, qd, taken)
+    on, oassign = O.search_by_projection_frame(ov, q, qd, taken, True)
+    assert n == on and np.array_equal(assign, oassign)
+    assert n > 300
+    q2 = q.copy(); q2["max_level"] = q2["min_level"] + 1                        # points overload: levels [pred-1, pred]
+    n, assign = m.SearchByProjectionPoints(gv, q2, qd, taken)
+    on, oassign = O.search_by_projection_points(ov, q2, qd, taken, 0.8)
+    assert n == on and np.array_equal(assign, oassign)
+    n, assign = m.SearchByProjectionKeyFrame(gv, q, qd, taken, ORBdist=64)
+    on, oassign = O.search_by_projection_block(ov, q, qd, taken, 64, True)
+    assert n == on and np.array_equal(assign, oassign)
+
+
+def test_search_for_initialization_keeps_its_limit(env):
+    """SearchForInitialization replays the match stealing over LDS state: more than 4096 keypoints is an explicit
+    E_CAPACITY (the initialiser extracts 2 x nFeatures = 2000, src/Tracking.cc:125)."""
     pkg, M, O = env
     n = 4100
     k = np.zeros(n, pkg.KP_DTYPE); k["x"] = np.arange(n) % 600 + 20; k["y"] = np.arange(n) // 600 * 5 + 20
     d = np.random.default_rng(0).integers(0, 256, (n, 32), dtype=np.uint8)
     fv = pkg.FrameView(k, d, np.ones(8, np.float32), (0, 0, 640, 480))
-    q = np.zeros(10, pkg.QUERY_DTYPE); q["valid"] = 1; q["u"] = 100; q["v"] = 50; q["radius"] = 10; q["min_level"] = -1; q["max_level"] = -1
     with pytest.raises(pkg.OrbHipError) as ei:
-        pkg.ORBmatcher().SearchByProjectionFrame(fv, q, d[:10])
+        pkg.ORBmatcher(0.9, True).SearchForInitialization(fv, fv, np.stack([k["x"], k["y"]], 1), 100)
     assert ei.value.code == -3
 
 
