@@ -12,6 +12,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <ctime>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -50,9 +51,10 @@ __device__ __forceinline__ int wave_reduce_add(int v)
     return v;
 }
 
-// Exclusive scan of one int per thread over a 256-thread block.  `sh` = 8 ints of LDS.
+// Exclusive scan of one int per thread over a T-thread block (T = 256, 512 or 1024).  `sh` = T / 64 ints of LDS.
 // Returns the exclusive prefix; *total receives the block sum.  Ends with a barrier.
-__device__ __forceinline__ int block_excl_scan256(int v, int *sh, int *total)
+template <int T>
+__device__ __forceinline__ int block_excl_scan(int v, int *sh, int *total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = v;
@@ -66,7 +68,7 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *sh, int *total)
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < T / 64; ++w) {
         int s = sh[w];
         if (w < wave) base += s;
         tot += s;
@@ -74,6 +76,7 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *sh, int *total)
     *total = tot;
     return base + incl - v;
 }
+__device__ __forceinline__ int block_excl_scan256(int v, int *sh, int *total) { return block_excl_scan<256>(v, sh, total); }
 
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
@@ -631,13 +634,13 @@ struct OctShared {
     unsigned short ord[MAXN];  // processing order -> node
     unsigned short rnk[MAXN];  // node -> processing rank (0xffff: not expandable)
     int cincl[MAXN];           // inclusive scan of child counts in processing order
-    int scan[8];
+    int scan[16];
     int vars[8];
     uint32_t lkeys[kOctKeysLds];        // candidate keys (x | y<<12 | score<<24) when they fit
     unsigned short lnode[kOctKeysLds];  // owning node of each key
 };
 
-template <int MAXN, bool INLDS>
+template <int MAXN, bool INLDS, int T>
 __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G, const LevelGeom &L,
                                             const int level, const int b, const int K,
                                             const int *__restrict__ ccnt_in, const uint32_t *__restrict__ ckp_in,
@@ -652,11 +655,11 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
     int tot;
     // gather the per-cell survivor lists into one array in reference order: flat loop over the K keys,
     // owning cell by binary search over the exclusive offsets in S.ccnt (loads stay independent)
-    for (int k0 = 0; k0 < K; k0 += 256 * 4) {
+    for (int k0 = 0; k0 < K; k0 += T * 4) {
         uint32_t v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * 256 + tid;
+            const int k = k0 + u * T + tid;
             v[u] = 0;
             if (k < K) {
                 int lo = 0, hi = L.ncells - 1;      // last cell c with S.ccnt[c] <= k
@@ -669,7 +672,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * 256 + tid;
+            const int k = k0 + u * T + tid;
             if (k < K) keys(k) = v[u];
         }
     }
@@ -678,7 +681,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
     // ---- initial nodes (:543-585) ----
     const int nIni = L.nIni;
     const int height = L.maxBY - 16;
-    for (int i = tid; i < nIni; i += 256) {
+    for (int i = tid; i < nIni; i += T) {
         S.x0[0][i] = (short)(int)__fmul_rn(L.hX, (float)i);
         S.x1[0][i] = (short)(int)__fmul_rn(L.hX, (float)(i + 1));
         S.y0[0][i] = 0;
@@ -686,13 +689,13 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         S.ccnt[i] = 0;
     }
     __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += 256 * kOctU) {
+    for (int k0 = 0; k0 < K; k0 += T * kOctU) {
         uint32_t kv[kOctU];
 #pragma unroll
-        for (int u = 0; u < kOctU; ++u) { const int k = k0 + u * 256 + tid; kv[u] = k < K ? keys(k) : 0u; }
+        for (int u = 0; u < kOctU; ++u) { const int k = k0 + u * T + tid; kv[u] = k < K ? keys(k) : 0u; }
 #pragma unroll
         for (int u = 0; u < kOctU; ++u) {
-            const int k = k0 + u * 256 + tid;
+            const int k = k0 + u * T + tid;
             if (k < K) {
                 const int bin = min((int)__fdiv_rn((float)(kv[u] & 0xfffu), L.hX), nIni - 1);
                 knode(k) = (unsigned short)bin;
@@ -705,10 +708,10 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
     {
         // drop empty initial nodes, keep order
         int carry = 0;
-        for (int i0 = 0; i0 < nIni; i0 += 256) {
+        for (int i0 = 0; i0 < nIni; i0 += T) {
             int i = i0 + tid;
             int c = i < nIni ? S.ccnt[i] : 0;
-            int pos = carry + block_excl_scan256(c > 0, S.scan, &tot);
+            int pos = carry + block_excl_scan<T>(c > 0, S.scan, &tot);
             if (i < nIni) {
                 S.nmap[i] = pos;
                 if (c > 0) {
@@ -721,14 +724,14 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         }
         n = carry;
         __syncthreads();
-        for (int k0 = 0; k0 < K; k0 += 256 * kOctU) {
+        for (int k0 = 0; k0 < K; k0 += T * kOctU) {
             int nd[kOctU];
 #pragma unroll
-            for (int u = 0; u < kOctU; ++u) { const int k = k0 + u * 256 + tid; nd[u] = k < K ? (int)knode(k) : 0; }
+            for (int u = 0; u < kOctU; ++u) { const int k = k0 + u * T + tid; nd[u] = k < K ? (int)knode(k) : 0; }
 #pragma unroll
             for (int u = 0; u < kOctU; ++u) nd[u] = S.nmap[nd[u]];
 #pragma unroll
-            for (int u = 0; u < kOctU; ++u) { const int k = k0 + u * 256 + tid; if (k < K) knode(k) = (unsigned short)nd[u]; }
+            for (int u = 0; u < kOctU; ++u) { const int k = k0 + u * T + tid; if (k < K) knode(k) = (unsigned short)nd[u]; }
         }
         __syncthreads();
     }
@@ -739,16 +742,16 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
     while (!finish) {
         const int prevSize = n;
         // A: zero child counters
-        for (int i = tid; i < n * 4; i += 256) S.ccnt[i] = 0;
+        for (int i = tid; i < n * 4; i += T) S.ccnt[i] = 0;
         __syncthreads();
         // B: count children of expandable nodes (DivideNode :481-526)
-        for (int k0 = 0; k0 < K; k0 += 256 * kOctU) {
+        for (int k0 = 0; k0 < K; k0 += T * kOctU) {
             // kOctU independent keys per thread: the LDS round trips of the chains overlap
             int nd[kOctU], cn[kOctU];
             uint32_t kv[kOctU];
 #pragma unroll
             for (int u = 0; u < kOctU; ++u) {
-                const int k = k0 + u * 256 + tid;
+                const int k = k0 + u * T + tid;
                 nd[u] = k < K ? (int)knode(k) : 0;
                 kv[u] = k < K ? keys(k) : 0u;
             }
@@ -762,7 +765,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
             }
 #pragma unroll
             for (int u = 0; u < kOctU; ++u) {
-                const int k = k0 + u * 256 + tid;
+                const int k = k0 + u * T + tid;
                 if (k < K && cn[u] > 1) {
                     const int x = kv[u] & 0xfff, y = (kv[u] >> 12) & 0xfff;
                     const int mx = bx0[u] + ((bx1[u] - bx0[u] + 1) >> 1), my = by0[u] + ((by1[u] - by0[u] + 1) >> 1);
@@ -775,10 +778,10 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         int m = 0;
         if (phase == 1) {
             int carry = 0;
-            for (int i0 = 0; i0 < n; i0 += 256) {
+            for (int i0 = 0; i0 < n; i0 += T) {
                 int i = i0 + tid;
                 int e = (i < n && S.cnt[cur][i] > 1) ? 1 : 0;
-                int r = carry + block_excl_scan256(e, S.scan, &tot);
+                int r = carry + block_excl_scan<T>(e, S.scan, &tot);
                 if (i < n) S.rnk[i] = e ? (unsigned short)r : (unsigned short)0xffff;
                 if (e) S.ord[r] = (unsigned short)i;
                 carry += tot;
@@ -788,7 +791,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
             // (size desc, list position asc): the reference sorts (size, node address) ascending
             // and walks from the back (:684-685); "newer node first" stands in for the address.
             int carry = 0;
-            for (int i0 = 0; i0 < n; i0 += 256) {
+            for (int i0 = 0; i0 < n; i0 += T) {
                 int i = i0 + tid;
                 int e = (i < n && S.cnt[cur][i] > 1) ? 1 : 0;
                 int r = 0;
@@ -802,7 +805,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
                     S.rnk[i] = (unsigned short)r;
                     S.ord[r] = (unsigned short)i;
                 } else if (i < n) S.rnk[i] = 0xffff;
-                int dummy = block_excl_scan256(e, S.scan, &tot);
+                int dummy = block_excl_scan<T>(e, S.scan, &tot);
                 (void)dummy;
                 carry += tot;
             }
@@ -813,14 +816,14 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         int Jfound = 0x7fffffff;
         {
             int carry = 0;
-            for (int j0 = 0; j0 < m; j0 += 256) {
+            for (int j0 = 0; j0 < m; j0 += T) {
                 int j = j0 + tid;
                 int nc = 0;
                 if (j < m) {
                     int nd = S.ord[j];
                     nc = (S.ccnt[4 * nd] > 0) + (S.ccnt[4 * nd + 1] > 0) + (S.ccnt[4 * nd + 2] > 0) + (S.ccnt[4 * nd + 3] > 0);
                 }
-                int ex = carry + block_excl_scan256(nc, S.scan, &tot);
+                int ex = carry + block_excl_scan<T>(nc, S.scan, &tot);
                 if (j < m) {
                     S.cincl[j] = ex + nc;
                     if (phase == 2 && n + ex + nc - (j + 1) >= N) Jfound = min(Jfound, j);
@@ -840,12 +843,12 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         int nToExpand = 0;
         {
             int carry = 0;
-            for (int i0 = 0; i0 < n; i0 += 256) {
+            for (int i0 = 0; i0 < n; i0 += T) {
                 int i = i0 + tid;
                 int split = 0;
                 if (i < n) { int r = S.rnk[i]; split = (r != 0xffff && r <= J); }
                 int surv = (i < n && !split) ? 1 : 0;
-                int spos = carry + block_excl_scan256(surv, S.scan, &tot);
+                int spos = carry + block_excl_scan<T>(surv, S.scan, &tot);
                 if (i < n) {
                     if (surv) {
                         int ni = Gc + spos;
@@ -881,12 +884,12 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         }
         __syncthreads();
         // F: relabel keys
-        for (int k0 = 0; k0 < K; k0 += 256 * kOctU) {
+        for (int k0 = 0; k0 < K; k0 += T * kOctU) {
             int nd[kOctU], mp[kOctU];
             uint32_t kv[kOctU];
 #pragma unroll
             for (int u = 0; u < kOctU; ++u) {
-                const int k = k0 + u * 256 + tid;
+                const int k = k0 + u * T + tid;
                 nd[u] = k < K ? (int)knode(k) : 0;
                 kv[u] = k < K ? keys(k) : 0u;
             }
@@ -901,7 +904,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
             }
 #pragma unroll
             for (int u = 0; u < kOctU; ++u) {
-                const int k = k0 + u * 256 + tid;
+                const int k = k0 + u * T + tid;
                 if (k >= K) continue;
                 if (mp[u] & 0x40000000) {
                     const int x = kv[u] & 0xfff, y = (kv[u] >> 12) & 0xfff;
@@ -930,27 +933,27 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
 
     // ---- retain the best key of every node, first index wins ties (:742-760) ----
     unsigned int *best = reinterpret_cast<unsigned int *>(S.ccnt);
-    for (int i = tid; i < n; i += 256) best[i] = 0;
+    for (int i = tid; i < n; i += T) best[i] = 0;
     __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += 256 * kOctU) {
+    for (int k0 = 0; k0 < K; k0 += T * kOctU) {
         int nd[kOctU];
         uint32_t kv[kOctU];
 #pragma unroll
         for (int u = 0; u < kOctU; ++u) {
-            const int k = k0 + u * 256 + tid;
+            const int k = k0 + u * T + tid;
             nd[u] = k < K ? (int)knode(k) : 0;
             kv[u] = k < K ? keys(k) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < kOctU; ++u) {
-            const int k = k0 + u * 256 + tid;
+            const int k = k0 + u * T + tid;
             if (k < K) atomicMax(&best[nd[u]], ((kv[u] >> 24) << 24) | (0xffffffu - (uint32_t)k));
         }
     }
     __syncthreads();
     uint32_t *out = sel_kp + (size_t)b * G.kp_cap_total + L.kp_base;
     const int nout = min(n, L.kp_cap);
-    for (int i = tid; i < nout; i += 256) out[i] = keys(0xffffffu - (best[i] & 0xffffffu));
+    for (int i = tid; i < nout; i += T) out[i] = keys(0xffffffu - (best[i] & 0xffffffu));
     if (tid == 0) {
         sel_cnt[b * ORBHIP_MAX_LEVELS + level] = nout;
         if (n > L.kp_cap) atomicExch(&frame_status[b], ORBHIP_E_CAPACITY);
@@ -959,8 +962,8 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
 #undef knode
 }
 
-template <int MAXN>
-__global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict__ cell_cnt,
+template <int MAXN, int T>
+__global__ __launch_bounds__(T) void k_octree(PyrGeom G, const int *__restrict__ cell_cnt,
                                                 const uint32_t *__restrict__ cell_kp,
                                                 uint32_t *__restrict__ keys_ws,
                                                 unsigned short *__restrict__ node_ws,
@@ -979,18 +982,18 @@ __global__ __launch_bounds__(256) void k_octree(PyrGeom G, const int *__restrict
     int tot;
     // ---- offsets of the per-cell survivor lists inside one array in reference order ----
     int K = 0;
-    for (int c0 = 0; c0 < L.ncells; c0 += 256) {
+    for (int c0 = 0; c0 < L.ncells; c0 += T) {
         int c = c0 + tid;
         int n = c < L.ncells ? ccnt_in[c] : 0;
-        int base = block_excl_scan256(n, S.scan, &tot);
+        int base = block_excl_scan<T>(n, S.scan, &tot);
         if (c < L.ncells) S.ccnt[c] = K + base;  // ncells <= MAXN*4 checked on the host
         K += tot;
     }
     __syncthreads();
     if (K <= kOctKeysLds)
-        octree_body<MAXN, true>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
+        octree_body<MAXN, true, T>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
     else
-        octree_body<MAXN, false>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
+        octree_body<MAXN, false, T>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
 }
 
 // ---------------------------------------------------------------------------
@@ -1407,6 +1410,13 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         maxn = std::max(maxn, std::max(L.kp_cap + 4, (L.ncells + 3) / 4));
     }
     G.cand_cap_total = std::max(cand_base, 1);
+    {   // workgroup size of the octree kernel: the level-0 workgroup is the critical path (all (level, frame) workgroups
+        // are co-resident); 512 threads halve its key loops (61 -> 54 us per 64 KITTI frames), 1024 would leave one
+        // workgroup per CU (75 us)
+        int max_cells = 0;
+        for (int l = 0; l < e->nlevels; ++l) max_cells = std::max(max_cells, G.lv[l].ncells);
+        e->octree_threads = max_cells >= 128 ? 512 : 256;
+    }
     if (maxn <= 512) e->octree_maxn = 512;
     else if (maxn <= 2048) e->octree_maxn = 2048;
     else { set_error("nfeatures too large for the octree kernel (per-level cap %d > 2048)", maxn); return ORBHIP_E_ARG; }
@@ -1503,12 +1513,17 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
 #undef ORBHIP_FAST2
     }
     if (prof) (void)hipEventRecord(ev[2], s);
-    if (e->octree_maxn == 512)
-        hipLaunchKernelGGL(k_octree<512>, dim3(G.nlevels, batch), dim3(256), 0, s, G, b_cell_cnt, b_cell_kp,
-                           b_keys, b_knode, b_sel, b_sel_cnt, status);
-    else
-        hipLaunchKernelGGL(k_octree<2048>, dim3(G.nlevels, batch), dim3(256), 0, s, G, b_cell_cnt, b_cell_kp,
-                           b_keys, b_knode, b_sel, b_sel_cnt, status);
+    {
+        const int ot = e->octree_threads;
+#define ORBHIP_OCT(MAXNv, Tv) hipLaunchKernelGGL((k_octree<MAXNv, Tv>), dim3(G.nlevels, batch), dim3(Tv), 0, s, G, b_cell_cnt, b_cell_kp, \
+                                                 b_keys, b_knode, b_sel, b_sel_cnt, status)
+        if (e->octree_maxn == 512) {
+            if (ot == 1024) ORBHIP_OCT(512, 1024); else if (ot == 512) ORBHIP_OCT(512, 512); else ORBHIP_OCT(512, 256);
+        } else {
+            if (ot == 1024) ORBHIP_OCT(2048, 1024); else if (ot == 512) ORBHIP_OCT(2048, 512); else ORBHIP_OCT(2048, 256);
+        }
+#undef ORBHIP_OCT
+    }
     if (prof) (void)hipEventRecord(ev[3], s);
     // The blur only needs the pyramid.  Forking it onto a second stream beside FAST/octree was measured: it buys
     // nothing once two pipelines (handles) run concurrently and makes throughput depend on how the runtime maps
@@ -1759,10 +1774,32 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
             e->ev_chunk.push_back(ev);
         }
         const size_t fbytes = (size_t)rows * cols;
+        static const bool host_timing = getenv("ORBHIP_HOST_TIMING") != nullptr;   // development: where the host time goes
+        double t_stage = 0, t_enq = 0, t_wait = 0, t_deliver = 0;
+        auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+        // a caller that keeps its images in page-locked memory (hipHostMalloc / hipHostRegister, e.g. a pinned cv::Mat
+        // allocator) skips the staging copy: the DMA engine reads the frames where they are
+        bool pinned_src = false;
+        {
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, images) == hipSuccess) pinned_src = attr.type == hipMemoryTypeHost;
+            else (void)hipGetLastError();   // pageable memory is "invalid value" for this query: not an error here
+        }
         for (int c = 0; c < nchunks; ++c) {
             const int b0 = c * kChunk, nb = std::min(kChunk, batch - b0);
             hipEvent_t ev_in = e->ev_chunk[3 * c], ev_k = e->ev_chunk[3 * c + 1], ev_out = e->ev_chunk[3 * c + 2];
-            stage_in(b0, nb);
+            const double t0 = now();
+            if (!pinned_src) stage_in(b0, nb);
+            const double t1 = now();
+            t_stage += t1 - t0;
+            if (pinned_src) {
+                if (stride == cols && frame_stride == fbytes)
+                    ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img + b0 * fbytes, images + b0 * frame_stride, nb * fbytes, hipMemcpyHostToDevice, e->s_in));
+                else
+                    for (int b = b0; b < b0 + nb; ++b)
+                        ORBHIP_HIP_CHECK(hipMemcpy2DAsync(e->d_img + b * fbytes, cols, images + b * frame_stride, stride, cols, rows,
+                                                          hipMemcpyHostToDevice, e->s_in));
+            } else
             ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img + b0 * fbytes, e->h_in + b0 * fbytes, nb * fbytes, hipMemcpyHostToDevice, e->s_in));
             ORBHIP_HIP_CHECK(hipEventRecord(ev_in, e->s_in));
             ORBHIP_HIP_CHECK(hipStreamWaitEvent(e->stream, ev_in, 0));
@@ -1778,13 +1815,20 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
             ORBHIP_HIP_CHECK(hipMemcpyAsync(h_desc + (size_t)b0 * cap * 32, e->d_odesc + (size_t)b0 * cap * 32, (size_t)nb * cap * 32,
                                             hipMemcpyDeviceToHost, e->s_out));
             ORBHIP_HIP_CHECK(hipEventRecord(ev_out, e->s_out));
+            t_enq += now() - t1;
         }
         int bad = -1;
         for (int c = 0; c < nchunks; ++c) {
+            const double t0 = now();
             ORBHIP_HIP_CHECK(hipEventSynchronize(e->ev_chunk[3 * c + 2]));
+            const double t1 = now();
             deliver(c * kChunk, std::min(kChunk, batch - c * kChunk), bad);
+            t_wait += t1 - t0; t_deliver += now() - t1;
         }
         ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+        if (host_timing)
+            fprintf(stderr, "[orbhip] extract_batch %d frames: stage-in %.3f ms, enqueue %.3f ms, wait %.3f ms, deliver %.3f ms\n",
+                    batch, t_stage, t_enq, t_wait, t_deliver);
         if (bad >= 0) { set_error("frame %d: capacity exceeded (cap %d); outputs are truncated", bad, cap); return ORBHIP_E_CAPACITY; }
         return ORBHIP_OK;
     }
@@ -1925,6 +1969,7 @@ int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *
 }
 
 // development switch (not part of include/orbhip.h): 1 = first formulation of the FAST kernel, 0 = current one
+int orbhip_dev_set_octree_threads(orbhip_extractor *e, int t) { if (!e) return ORBHIP_E_ARG; e->octree_threads = t; return ORBHIP_OK; }
 int orbhip_dev_set_fast_variant(orbhip_extractor *e, int v)
 {
     if (!e) return ORBHIP_E_ARG;

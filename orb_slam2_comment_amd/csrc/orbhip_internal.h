@@ -55,6 +55,7 @@ struct orbhip_extractor {
     std::vector<orbhip::CellDesc> cells;
     std::vector<orbhip::TileDesc> tiles;
     int octree_maxn = 512;
+    int octree_threads = 256;   // workgroup size of k_octree (256 / 512 / 1024)
     orbhip::FastLds fast_lds;   // k_fast_cells dynamic LDS carve-up
     int fast_lds_bytes = 0;
     int fast_variant = 0;       // development switch (tools/fast_ab.py): 2 stamped build, 3 / 4 timing floors

@@ -75,14 +75,13 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
-// Visiting order of Frame::GetFeaturesInArea (cell-major ix outer / iy inner, insertion
-// order inside a cell; Frame.cc:350-358) as a sortable key: (posX*48+posY) << 20 | index.
-// Keypoints that PosInGrid rejects (Frame.cc:382-392) are never candidates.
+// Visiting-order key of every train keypoint, (posX*48+posY) << 20 | index, or kNoCell when PosInGrid rejects it
+// (k_best_in_window scans the frame with it).
 __global__ void k_grid_order(DevFrame F, uint32_t *__restrict__ ord, Batch B)
 {
     batch_frame(F, B, blockIdx.y);
     ord += (size_t)blockIdx.y * B.cap;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= F.n) return;
     const orbhip_keypoint kp = F.keys[j];
     int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.min_x), F.inv_w));
@@ -91,23 +90,98 @@ __global__ void k_grid_order(DevFrame F, uint32_t *__restrict__ ord, Batch B)
     ord[j] = in ? (((uint32_t)(px * GRID_ROWS + py) << 20) | (uint32_t)j) : kNoCell;
 }
 
-// One wavefront per query.  Output: cand[q*stride + i] = dist << 32 | order key, sorted
-// ascending when the query has <= 64 candidates (cnt[q] > 0), unsorted otherwise (cnt[q] < 0,
-// magnitude = count).
-__global__ __launch_bounds__(256) void k_window_search(DevFrame F, const uint32_t *__restrict__ ord,
+// mGrid of the train frame (Frame::AssignFeaturesToGrid, Frame.cc:230-245) as CSR, one workgroup per frame: cell
+// c = posX * 48 + posY owns the records rec[start[c] .. start[c+1]).  A record carries everything the window search
+// needs of a keypoint -- (x, y, octave, index) and, in a parallel array, its descriptor -- so a query reads its
+// candidates with addresses that depend on the cell table only (one memory round trip, not index -> keypoint ->
+// descriptor).  Counting sort with LDS atomics; the order INSIDE a cell is arbitrary: every consumer orders candidates
+// by the key (cell << 20 | index) = the visiting order of Frame::GetFeaturesInArea (cell-major ix outer / iy inner,
+// insertion order inside a cell; Frame.cc:350-358).  Keypoints that PosInGrid rejects (Frame.cc:382-392) are in no
+// cell and never candidates.
+constexpr int kGridCells = GRID_COLS * GRID_ROWS;
+struct GridRec { float x, y; int octave; uint32_t key; };   // key = cell << 20 | index
+__global__ __launch_bounds__(256) void k_grid_build(DevFrame F, int *__restrict__ cell_start, GridRec *__restrict__ rec,
+                                                    uint4 *__restrict__ rdesc, float *__restrict__ rur, Batch B)
+{
+    __shared__ int s_cnt[kGridCells];
+    __shared__ int s_scan[8];
+    const int tid = threadIdx.x, pair = blockIdx.x;
+    batch_frame(F, B, pair);
+    const size_t rbase = (size_t)pair * (B.cap > 0 ? B.cap : F.n);
+    cell_start += (size_t)pair * (kGridCells + 1);
+    rec += rbase; rdesc += rbase * 2; rur += rbase;
+    for (int c = tid; c < kGridCells; c += 256) s_cnt[c] = 0;
+    __syncthreads();
+    for (int j = tid; j < F.n; j += 256) {
+        const orbhip_keypoint kp = F.keys[j];
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.min_x), F.inv_w));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, F.min_y), F.inv_h));
+        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) atomicAdd(&s_cnt[px * GRID_ROWS + py], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the 3072 cells: 12 consecutive cells per thread
+    constexpr int PER = kGridCells / 256;
+    int local[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { local[k] = s_cnt[tid * PER + k]; sum += local[k]; }
+    int incl = sum;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wave; ++w) base += s_scan[w];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { s_cnt[tid * PER + k] = base; cell_start[tid * PER + k] = base; base += local[k]; }
+    if (tid == 255) cell_start[kGridCells] = base;
+    __syncthreads();
+    for (int j = tid; j < F.n; j += 256) {
+        const orbhip_keypoint kp = F.keys[j];
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.min_x), F.inv_w));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, F.min_y), F.inv_h));
+        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) {
+            const int cell = px * GRID_ROWS + py;
+            const int pos = atomicAdd(&s_cnt[cell], 1);
+            GridRec r; r.x = kp.x; r.y = kp.y; r.octave = kp.octave; r.key = ((uint32_t)cell << 20) | (uint32_t)j;
+            rec[pos] = r;
+            const uint4 *d = reinterpret_cast<const uint4 *>(F.desc + (size_t)j * 32);
+            rdesc[2 * pos] = d[0]; rdesc[2 * pos + 1] = d[1];
+            rur[pos] = F.u_right ? F.u_right[j] : -1.0f;
+        }
+    }
+}
+
+// One wavefront per query.  The cells of the query's window (Frame.cc:332-346) are dealt to the lanes; the records of
+// all those cells are then flattened over the lanes (wave prefix sum of the cell populations + an LDS scatter of the
+// record positions), so one pass tests 64 candidates: level window, |dx|,|dy| < r, stereo gate, Hamming distance.
+// Output: dist << 32 | (cell << 20 | index) keys; with <= 64 candidates the list is bitonic-sorted (= (distance,
+// reference visiting order)) into ccand[q*64 ..] and cnt[q] > 0, otherwise it stays unsorted in cand[q*stride ..] with
+// cnt[q] = -count.
+constexpr int kCompact = 64;
+__global__ __launch_bounds__(256) void k_window_search(DevFrame F, const int *__restrict__ cell_start,
+                                                       const GridRec *__restrict__ rec, const uint4 *__restrict__ rdesc,
+                                                       const float *__restrict__ rur,
                                                        const orbhip_query *__restrict__ q,
                                                        const uint8_t *__restrict__ qdesc, int nq,
                                                        unsigned long long *__restrict__ cand,
+                                                       unsigned long long *__restrict__ ccand,
                                                        int *__restrict__ cnt, int stride, int use_ur, Batch B)
 {
     __shared__ unsigned long long stage[4][64];
+    __shared__ int spos[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int pair = blockIdx.y;
+    const bool has_ur = F.u_right != nullptr;
     batch_frame(F, B, pair);
-    ord += (size_t)pair * B.cap;
+    const size_t rbase = (size_t)pair * (B.cap > 0 ? B.cap : F.n);
+    cell_start += (size_t)pair * (kGridCells + 1);
+    rec += rbase; rdesc += rbase * 2; rur += rbase;
     q += (size_t)pair * B.qcap;
     qdesc += (size_t)(B.qd0 + pair * B.qds) * B.qcap * 32;
     cand += (size_t)pair * B.qcap * stride;
+    ccand += (size_t)pair * B.qcap * kCompact;
     cnt += (size_t)pair * B.qcap;
     if (B.nq_dev) nq = min(B.nq_dev[pair], B.qcap);
     const int qi = blockIdx.x * 4 + wv;
@@ -120,7 +194,8 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const uint32_
     const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, F.min_x), r), F.inv_w)));
     const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, F.min_y), r), F.inv_h)));
     const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, F.min_y), r), F.inv_h)));
-    if (nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0) {
+    if (nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0 || nMaxCellX < nMinCellX ||
+        nMaxCellY < nMinCellY) {
         if (lane == 0) cnt[qi] = 0;
         return;
     }
@@ -130,49 +205,66 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const uint32_
 #pragma unroll
     for (int i = 0; i < 8; ++i) qd[i] = qp[i];
     unsigned long long *out = cand + (size_t)qi * stride;
+    const int ncy = nMaxCellY - nMinCellY + 1, ncell = (nMaxCellX - nMinCellX + 1) * ncy;
     int total = 0;
-    for (int j0 = 0; j0 < F.n; j0 += 64) {
-        const int j = j0 + lane;
-        bool ok = false;
-        unsigned long long key = 0;
-        if (j < F.n) {
-            const uint32_t o = ord[j];
-            if (o != kNoCell) {
-                const int cell = (int)(o >> 20);
-                const int px = cell / GRID_ROWS, py = cell - px * GRID_ROWS;
-                const orbhip_keypoint kp = F.keys[j];
-                ok = px >= nMinCellX && px <= nMaxCellX && py >= nMinCellY && py <= nMaxCellY;
+    // a column of the window is a contiguous run of cells (cell = ix * 48 + iy), so its records are one contiguous CSR
+    // range: lane = window column, range = [start[ix*48 + y0], start[ix*48 + y1 + 1])
+    const int ncol = nMaxCellX - nMinCellX + 1;
+    (void)ncell;
+    for (int c0 = 0; c0 < ncol; c0 += 64) {
+        const int c = c0 + lane;
+        int start = 0, ncand = 0;
+        if (c < ncol) {
+            const int cell0 = (nMinCellX + c) * GRID_ROWS + nMinCellY;
+            start = cell_start[cell0];
+            ncand = cell_start[cell0 + ncy] - start;
+        }
+        // exclusive prefix of the column populations over the wave
+        int incl = ncand;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+        const int nrec = __shfl(incl, 63, 64);
+        const int excl = incl - ncand;
+        for (int r0 = 0; r0 < nrec; r0 += 64) {
+            // scatter: flat record t of this chunk comes from CSR position spos[t - r0]
+            __builtin_amdgcn_wave_barrier();
+            for (int k = max(0, r0 - excl); k < ncand && excl + k < r0 + 64; ++k) spos[wv][excl + k - r0] = start + k;
+            __builtin_amdgcn_wave_barrier();
+            bool ok = false;
+            unsigned long long key = 0;
+            if (r0 + lane < nrec) {
+                const int p = spos[wv][lane];
+                const GridRec R = rec[p];
+                const uint4 d0 = rdesc[2 * p], d1 = rdesc[2 * p + 1];
+                ok = true;
                 if (bCheckLevels) {
-                    if (kp.octave < Q.min_level) ok = false;
-                    if (Q.max_level >= 0 && kp.octave > Q.max_level) ok = false;
+                    if (R.octave < Q.min_level) ok = false;
+                    if (Q.max_level >= 0 && R.octave > Q.max_level) ok = false;
                 }
-                ok = ok && fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r;
-                if (ok && use_ur && F.u_right) {
-                    const float ur = F.u_right[j];
+                ok = ok && fabsf(__fsub_rn(R.x, x)) < r && fabsf(__fsub_rn(R.y, y)) < r;
+                if (ok && use_ur && has_ur) {
+                    const float ur = rur[p];
                     if (ur > 0 && fabsf(__fsub_rn(Q.ur, ur)) > r) ok = false;
                 }
-                if (ok) {
-                    const uint32_t *tp = reinterpret_cast<const uint32_t *>(F.desc + (size_t)j * 32);
-                    uint32_t td[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) td[i] = tp[i];
-                    key = ((unsigned long long)hamming256(qd, td) << 32) | o;
-                }
+                const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
+                                 __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
+                key = ((unsigned long long)dist << 32) | R.key;
             }
+            const unsigned long long bal = __ballot(ok);
+            if (ok) {
+                const int pos = total + __popcll(bal & ((1ull << lane) - 1ull));
+                out[pos] = key;
+                if (pos < 64) stage[wv][pos] = key;
+            }
+            total += __popcll(bal);
         }
-        const unsigned long long bal = __ballot(ok);
-        if (ok) {
-            const int pos = total + __popcll(bal & ((1ull << lane) - 1ull));
-            out[pos] = key;
-            if (pos < 64) stage[wv][pos] = key;
-        }
-        total += __popcll(bal);
     }
     if (total > 0 && total <= 64) {
-        // wave bitonic sort of up to 64 keys (pad with ~0)
+        // wave bitonic sort of up to 64 keys (pad with ~0); short lists sort in a narrower network
         __builtin_amdgcn_wave_barrier();
         unsigned long long v = lane < total ? stage[wv][lane] : ~0ull;
-        for (int k = 2; k <= 64; k <<= 1)
+        const int width = total <= 8 ? 8 : total <= 16 ? 16 : total <= 32 ? 32 : 64;
+        for (int k = 2; k <= width; k <<= 1)
             for (int jj = k >> 1; jj > 0; jj >>= 1) {
                 unsigned long long o = __shfl_xor(v, jj, 64);
                 const bool up = ((lane & k) == 0);
@@ -180,7 +272,7 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const uint32_
                 const unsigned long long mn = o < v ? o : v, mx = o < v ? v : o;
                 v = (lower == up) ? mn : mx;
             }
-        if (lane < total) out[lane] = v;
+        if (lane < total) ccand[(size_t)qi * kCompact + lane] = v;
         if (lane == 0) cnt[qi] = total;
     } else if (lane == 0) {
         cnt[qi] = -total;
@@ -670,6 +762,7 @@ __device__ __forceinline__ void three_maxima(const int *h, int &ind1, int &ind2,
 __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbhip_keypoint *__restrict__ qkeys,
                                                 const orbhip_query *__restrict__ q, int nq,
                                                 const unsigned long long *__restrict__ cand,
+                                                const unsigned long long *__restrict__ ccand,
                                                 const int *__restrict__ cnt, int stride,
                                                 const uint8_t *__restrict__ taken_in, float nnratio,
                                                 int check_ori, int *__restrict__ out, int *__restrict__ out_n, Batch B)
@@ -683,6 +776,7 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
         if (qkeys) qkeys += (size_t)(B.qd0 + pair * B.qds) * B.qcap;
         q += (size_t)pair * B.qcap;
         cand += (size_t)pair * B.qcap * stride;
+        ccand += (size_t)pair * B.qcap * kCompact;
         cnt += (size_t)pair * B.qcap;
         if (taken_in) taken_in += (size_t)pair * B.cap;
         out += (size_t)pair * (mode == 2 ? B.qcap : B.cap);
@@ -708,13 +802,13 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
     int nmatches = 0;
     // software prefetch: the list head of query i+1 is in flight while query i is resolved
     int c_next = nq > 0 ? S.q_cnt[0] : 0;
-    unsigned long long v_next = (c_next > 0 && lane < c_next) ? cand[lane] : ~0ull;
+    unsigned long long v_next = (c_next > 0 && lane < c_next) ? ccand[lane] : ~0ull;   // sorted lists live in the compact array
     for (int i = 0; i < nq; ++i) {
         const int c = c_next;
         const unsigned long long v = v_next;
         if (i + 1 < nq) {
             c_next = S.q_cnt[i + 1];
-            v_next = (c_next > 0 && lane < c_next) ? cand[(size_t)(i + 1) * stride + lane] : ~0ull;
+            v_next = (c_next > 0 && lane < c_next) ? ccand[(size_t)(i + 1) * kCompact + lane] : ~0ull;
         }
         if (c == 0) continue;
         const unsigned long long *list = cand + (size_t)i * stride;
@@ -839,6 +933,7 @@ __device__ __forceinline__ void resolve_par_carve(ResolveParState &S, unsigned c
 template <bool GS>
 __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, const orbhip_query *__restrict__ q, int nq,
                                                       const unsigned long long *__restrict__ cand,
+                                                      const unsigned long long *__restrict__ ccand,
                                                       const int *__restrict__ cnt, int stride,
                                                       const uint8_t *__restrict__ taken_in, float nnratio,
                                                       int check_ori, int *__restrict__ out, int *__restrict__ out_n, Batch B,
@@ -852,6 +947,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
         batch_frame(F, B, pair);
         q += (size_t)pair * B.qcap;
         cand += (size_t)pair * B.qcap * stride;
+        if (ccand) ccand += (size_t)pair * B.qcap * kCompact;
         cnt += (size_t)pair * B.qcap;
         if (taken_in) taken_in += (size_t)pair * B.cap;
         out += (size_t)pair * B.cap;
@@ -877,20 +973,35 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     if (tid < HISTO_LENGTH) S.hist[tid] = 0;
     if (tid == 0) { S.vars[1] = 0; S.vars[2] = 0; }
     __syncthreads();
+    // the head of this thread's first query list stays in registers: every round re-walks the list, and in the common
+    // case the answer is among its first entries (sorted lists only)
+    constexpr int kHead = 4;
+    unsigned long long head[kHead];
+    int head_c = 0;
+    if (tid < nq) {
+        head_c = cnt[tid];
+        if (head_c > 0) {
+            const unsigned long long *l0 = ccand ? ccand + (size_t)tid * kCompact : cand + (size_t)tid * stride;
+#pragma unroll
+            for (int e = 0; e < kHead; ++e) head[e] = e < head_c ? l0[e] : ~0ull;
+        }
+    }
     int cur = 0;
     for (int round = 0; round <= nq + 1; ++round) {
         if (tid == 0) S.vars[0] = 0;
         for (int c = tid; c < n; c += T) S.owner[cur ^ 1][c] = INT_MAX;
         __syncthreads();
         for (int i = tid; i < nq; i += T) {
-            const int c = cnt[i];
+            const int c = i == tid ? head_c : cnt[i];
             int newc = -1;
             if (c != 0) {
-                const unsigned long long *list = cand + (size_t)i * stride;
+                const unsigned long long *list = (c > 0 && ccand) ? ccand + (size_t)i * kCompact : cand + (size_t)i * stride;
                 unsigned long long k1 = ~0ull, k2 = ~0ull;
                 if (c > 0) {   // sorted: walk until two usable candidates are found
                     for (int e = 0; e < c; ++e) {
-                        const unsigned long long v = list[e];
+                        unsigned long long v;
+                        if (i == tid && e < kHead) v = e == 0 ? head[0] : e == 1 ? head[1] : e == 2 ? head[2] : head[3];
+                        else v = list[e];
                         const int idx = (int)(v & 0xfffffu);
                         if (S.taken[idx] || S.owner[cur][idx] < i) continue;
                         if (k1 == ~0ull) { k1 = v; if (mode == 0 || mode == 4) break; }
@@ -1041,7 +1152,7 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__
 // Frame::AssignFeaturesToGrid (Frame.cc:230-245): mGrid[64][48] as CSR.  One workgroup per frame: keys
 // (cell << 12 | index) are bitonic-sorted in LDS, which is push_back order inside every cell; cell sizes come from LDS
 // atomics and an exclusive scan.
-constexpr int kGridMax = 4096, kGridCells = GRID_COLS * GRID_ROWS;
+constexpr int kGridMax = 4096;
 __global__ __launch_bounds__(1024) void k_grid_csr(DevFrame F, Batch B, int *__restrict__ cell_of,
                                                    int *__restrict__ cell_start, int *__restrict__ cell_items)
 {
@@ -1630,7 +1741,7 @@ static int scratch(orbhip_matcher *m, int slot, size_t bytes, void **out)
     return ORBHIP_OK;
 }
 
-enum { S_KEYS = 0, S_DESC, S_UR, S_ORD, S_Q, S_QDESC, S_CAND, S_CNT, S_TAKEN, S_OUT, S_QKEYS, S_MISC, S_STATE, S_NSLOTS };
+enum { S_KEYS = 0, S_DESC, S_UR, S_ORD, S_Q, S_QDESC, S_CAND, S_CNT, S_TAKEN, S_OUT, S_QKEYS, S_MISC, S_STATE, S_CSR, S_CCAND, S_NSLOTS };
 
 static int stage_begin(orbhip_matcher *m, size_t total, Stage *st)
 {
@@ -1679,22 +1790,48 @@ static int ensure_resolve_attr(orbhip_matcher *m)
 
 // launch of the parallel resolve: LDS state up to kResolveMax train keypoints / queries, HBM state beyond
 static int launch_resolve_par(orbhip_matcher *m, int pairs, int mode, const DevFrame &D, const orbhip_query *d_q, int nq,
-                              int n_train, const unsigned long long *d_cand, const int *d_cnt, int stride,
+                              int n_train, const unsigned long long *d_cand, const unsigned long long *d_ccand,
+                              const int *d_cnt, int stride,
                               const uint8_t *d_taken, float nnratio, int check_ori, int *d_out, int *d_out_n, const Batch &B,
                               int th_accept, int all_block)
 {
     if (n_train <= kResolveMax && nq <= kResolveMax) {
         hipLaunchKernelGGL(k_resolve_par<false>, dim3(pairs), dim3(1024), resolve_par_bytes(kResolveMax, kResolveMax), m->stream,
-                           mode, D, d_q, nq, d_cand, d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out_n, B, th_accept,
+                           mode, D, d_q, nq, d_cand, d_ccand, d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out_n, B, th_accept,
                            all_block, (unsigned char *)nullptr, (size_t)0);
     } else {
         const size_t per = al256(resolve_par_bytes((size_t)n_train, (size_t)nq));
         void *p;
         int rc = scratch(m, S_STATE, per * (size_t)pairs, &p);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_resolve_par<true>, dim3(pairs), dim3(1024), 0, m->stream, mode, D, d_q, nq, d_cand, d_cnt, stride,
-                           d_taken, nnratio, check_ori, d_out, d_out_n, B, th_accept, all_block, (unsigned char *)p, per);
+        hipLaunchKernelGGL(k_resolve_par<true>, dim3(pairs), dim3(1024), 0, m->stream, mode, D, d_q, nq, d_cand, d_ccand, d_cnt,
+                           stride, d_taken, nnratio, check_ori, d_out, d_out_n, B, th_accept, all_block, (unsigned char *)p, per);
     }
+    return ORBHIP_OK;
+}
+
+// CSR grid of the train frames + the cell-window search: candidates of every query
+static int launch_window_search(orbhip_matcher *m, int pairs, const DevFrame &D, int n_train_cap, const orbhip_query *d_q,
+                                const uint8_t *d_qdesc, int nq, unsigned long long *d_cand, int *d_cnt, int stride, int use_ur,
+                                const Batch &B, unsigned long long **d_ccand_out)
+{
+    void *p;
+    int rc;
+    // CSR workspace per pair: cell table, records (16 B), descriptors (32 B), uRight (4 B) in CSR order
+    const size_t start_bytes = al256((size_t)pairs * (kGridCells + 1) * sizeof(int));
+    const size_t nrec = (size_t)pairs * n_train_cap;
+    if ((rc = scratch(m, S_CSR, start_bytes + al256(nrec * sizeof(GridRec)) + al256(nrec * 32) + al256(nrec * 4), &p))) return rc;
+    static_assert(sizeof(GridRec) == 16, "GridRec is one dwordx4");
+    int *d_start = (int *)p;
+    GridRec *d_rec = (GridRec *)((uint8_t *)p + start_bytes);
+    uint4 *d_rdesc = (uint4 *)((uint8_t *)d_rec + al256(nrec * sizeof(GridRec)));
+    float *d_rur = (float *)((uint8_t *)d_rdesc + al256(nrec * 32));
+    if ((rc = scratch(m, S_CCAND, (size_t)pairs * nq * kCompact * sizeof(unsigned long long), &p))) return rc;
+    unsigned long long *d_ccand = (unsigned long long *)p;
+    hipLaunchKernelGGL(k_grid_build, dim3(pairs), dim3(256), 0, m->stream, D, d_start, d_rec, d_rdesc, d_rur, B);
+    hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4, pairs), dim3(256), 0, m->stream, D, d_start, d_rec, d_rdesc, d_rur, d_q,
+                       d_qdesc, nq, d_cand, d_ccand, d_cnt, stride, use_ur, B);
+    *d_ccand_out = d_ccand;
     return ORBHIP_OK;
 }
 
@@ -1755,8 +1892,6 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
     const orbhip_keypoint *d_qkeys = qkeys ? (const orbhip_keypoint *)st.put(qkeys, (size_t)nq * sizeof(orbhip_keypoint)) : nullptr;
     if ((rc = stage_commit(m, &st))) return rc;
     void *p;
-    if ((rc = scratch(m, S_ORD, n * sizeof(uint32_t), &p))) return rc;
-    uint32_t *d_ord = (uint32_t *)p;
     const int stride = (train->n + 1) & ~1;
     if ((rc = scratch(m, S_CAND, (size_t)nqv * stride * sizeof(unsigned long long), &p))) return rc;
     unsigned long long *d_cand = (unsigned long long *)p;
@@ -1767,15 +1902,15 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
     uint8_t *h_out;
     if ((rc = out_buffer(m, (size_t)(nout + 1) * sizeof(int), &h_out))) return rc;
     const Batch one = {nullptr, nullptr, 0, 0};
-    hipLaunchKernelGGL(k_grid_order, dim3((train->n + 255) / 256), dim3(256), 0, m->stream, D, d_ord, one);
-    hipLaunchKernelGGL(k_window_search, dim3((nqv + 3) / 4), dim3(256), 0, m->stream, D, d_ord, d_q, d_qdesc, nqv, d_cand,
-                       d_cnt, stride, mode != 2 && use_ur, one);
+    unsigned long long *d_ccand;
+    if ((rc = launch_window_search(m, 1, D, train->n, d_q, d_qdesc, nqv, d_cand, d_cnt, stride, mode != 2 && use_ur, one, &d_ccand)))
+        return rc;
     if ((rc = ensure_resolve_attr(m))) return rc;
     if (mode == 2)   // SearchForInitialization: match stealing depends on the running minimum distance -> serial replay
         hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(ResolveShared), m->stream, mode, D, d_qkeys, d_q, nq, d_cand,
-                           d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout, one);
-    else if ((rc = launch_resolve_par(m, 1, mode, D, d_q, nqv, train->n, d_cand, d_cnt, stride, d_taken, nnratio, check_ori, d_out,
-                                      d_out + nout, one, th_accept, all_block)))
+                           d_ccand, d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout, one);
+    else if ((rc = launch_resolve_par(m, 1, mode, D, d_q, nqv, train->n, d_cand, d_ccand, d_cnt, stride, d_taken, nnratio, check_ori,
+                                      d_out, d_out + nout, one, th_accept, all_block)))
         return rc;
     ORBHIP_HIP_CHECK(hipGetLastError());
     ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)(nout + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
@@ -1955,8 +2090,8 @@ static int run_tri(orbhip_matcher *m, const TriParams *tri, const orbhip_frame_v
     if ((rc = ensure_resolve_attr(m))) return rc;
     hipLaunchKernelGGL(k_tri_search, dim3((nq + 3) / 4), dim3(256), 0, m->stream, D, d_tnode, d_mask, d_q, d_qdesc, nq,
                        d_cand, d_cnt, stride, *tri);
-    if ((rc = launch_resolve_par(m, 1, 4, D, d_q, nq, f2->n, d_cand, d_cnt, stride, (const uint8_t *)nullptr, 0.f, check_ori, d_out,
-                                 d_out + nq, one, TH_LOW, 0)))
+    if ((rc = launch_resolve_par(m, 1, 4, D, d_q, nq, f2->n, d_cand, nullptr, d_cnt, stride, (const uint8_t *)nullptr, 0.f, check_ori,
+                                 d_out, d_out + nq, one, TH_LOW, 0)))
         return rc;
     ORBHIP_HIP_CHECK(hipGetLastError());
     ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_out, (size_t)(nq + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
@@ -2392,8 +2527,6 @@ static int search_device(orbhip_matcher *m, int mode, int pairs, const void *d_k
     ORBHIP_HIP_CHECK(hipSetDevice(m->device));
     int rc;
     void *p;
-    if ((rc = scratch(m, S_ORD, (size_t)pairs * cap * sizeof(uint32_t), &p))) return rc;
-    uint32_t *d_ord = (uint32_t *)p;
     const int stride = (cap + 1) & ~1;
     if ((rc = scratch(m, S_CAND, (size_t)pairs * qcap * stride * sizeof(unsigned long long), &p))) return rc;
     unsigned long long *d_cand = (unsigned long long *)p;
@@ -2404,10 +2537,11 @@ static int search_device(orbhip_matcher *m, int mode, int pairs, const void *d_k
     D.n = cap; D.keys = (const orbhip_keypoint *)d_kps; D.desc = (const uint8_t *)d_desc; D.u_right = (const float *)d_u_right;
     D.min_x = min_x; D.min_y = min_y; D.inv_w = grid_inv_w; D.inv_h = grid_inv_h;
     const Batch B = {(const int *)d_n, (const int *)d_nq, cap, qcap, t0, ts, qd0, qds};
-    hipLaunchKernelGGL(k_grid_order, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, D, d_ord, B);
-    hipLaunchKernelGGL(k_window_search, dim3((qcap + 3) / 4, pairs), dim3(256), 0, m->stream, D, d_ord, (const orbhip_query *)d_q,
-                       (const uint8_t *)d_qdesc, qcap, d_cand, d_cnt, stride, 1, B);
-    if ((rc = launch_resolve_par(m, pairs, mode, D, (const orbhip_query *)d_q, qcap, cap, d_cand, d_cnt, stride,
+    unsigned long long *d_ccand;
+    if ((rc = launch_window_search(m, pairs, D, cap, (const orbhip_query *)d_q, (const uint8_t *)d_qdesc, qcap, d_cand, d_cnt, stride, 1,
+                                   B, &d_ccand)))
+        return rc;
+    if ((rc = launch_resolve_par(m, pairs, mode, D, (const orbhip_query *)d_q, qcap, cap, d_cand, d_ccand, d_cnt, stride,
                                  (const uint8_t *)d_taken, nnratio, check_ori, (int *)d_assign, (int *)d_nmatches, B, TH_HIGH, 0)))
         return rc;
     ORBHIP_HIP_CHECK(hipGetLastError());
@@ -2493,8 +2627,6 @@ int orbhip_search_for_initialization_device(orbhip_matcher *m, int pairs, const 
     ORBHIP_HIP_CHECK(hipSetDevice(m->device));
     int rc;
     void *p;
-    if ((rc = scratch(m, S_ORD, (size_t)pairs * cap * sizeof(uint32_t), &p))) return rc;
-    uint32_t *d_ord = (uint32_t *)p;
     const int stride = (cap + 1) & ~1;
     if ((rc = scratch(m, S_CAND, (size_t)pairs * cap * stride * sizeof(unsigned long long), &p))) return rc;
     unsigned long long *d_cand = (unsigned long long *)p;
@@ -2512,10 +2644,9 @@ int orbhip_search_for_initialization_device(orbhip_matcher *m, int pairs, const 
     D.n = cap; D.keys = keys; D.desc = (const uint8_t *)d_desc; D.u_right = nullptr;
     D.min_x = min_x; D.min_y = min_y; D.inv_w = grid_inv_w; D.inv_h = grid_inv_h;
     const Batch B = {(const int *)d_n, d_nq, cap, cap, f2_first, f2_step, f1_first, f1_step};
-    hipLaunchKernelGGL(k_grid_order, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, D, d_ord, B);
-    hipLaunchKernelGGL(k_window_search, dim3((cap + 3) / 4, pairs), dim3(256), 0, m->stream, D, d_ord, d_q,
-                       (const uint8_t *)d_desc, cap, d_cand, d_cnt, stride, 0, B);
-    hipLaunchKernelGGL(k_resolve, dim3(pairs), dim3(64), sizeof(ResolveShared), m->stream, 2, D, keys, d_q, cap, d_cand, d_cnt,
+    unsigned long long *d_ccand;
+    if ((rc = launch_window_search(m, pairs, D, cap, d_q, (const uint8_t *)d_desc, cap, d_cand, d_cnt, stride, 0, B, &d_ccand))) return rc;
+    hipLaunchKernelGGL(k_resolve, dim3(pairs), dim3(64), sizeof(ResolveShared), m->stream, 2, D, keys, d_q, cap, d_cand, d_ccand, d_cnt,
                        stride, (const uint8_t *)nullptr, nnratio, check_ori, (int *)d_matches12, (int *)d_nmatches, B);
     hipLaunchKernelGGL(k_init_update_prev, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, keys, cap, f2_first, f2_step,
                        d_nq, (const int *)d_matches12, (float *)d_prev_matched);

@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--calls", type=int, default=20)
-    ap.add_argument("--variants", default="0,3,4")
+    ap.add_argument("--variants", default="0,3,4", help="FAST development variants; 1000 + T selects the octree workgroup size T "
+                                                       "(256 / 512 / 1024) with the product FAST kernel")
     ap.add_argument("--size", default="1241x376")
     ap.add_argument("--nfeatures", type=int, default=1000)
     args = ap.parse_args()
@@ -46,26 +47,34 @@ def main():
     L = lib()
     variants = [int(v) for v in args.variants.split(",")]
 
+    def select(v):
+        if v >= 1000:
+            L.orbhip_dev_set_fast_variant(ext._h, 0)
+            L.orbhip_dev_set_octree_threads(ext._h, v - 1000)
+        else:
+            L.orbhip_dev_set_octree_threads(ext._h, 256)
+            L.orbhip_dev_set_fast_variant(ext._h, v)
+
     def run():
         ext.extract_batch_device(d_img.data_ptr(), B, H, W, d_k.data_ptr(), d_d.data_ptr(), cap, d_n.data_ptr(), d_s.data_ptr())
 
     ref = None
     res = {v: [] for v in variants}
     for v in variants:                         # results must not depend on the variant
-        L.orbhip_dev_set_fast_variant(ext._h, v)
+        select(v)
         run()
         torch.cuda.synchronize()
         sig = (d_n.cpu().numpy().copy(), d_d.cpu().numpy().copy(), d_k.cpu().numpy().copy())
         if ref is None:
             ref = sig
-        elif v < 3:
+        elif v < 3 or v >= 1000:
             n = ref[0]
             same = np.array_equal(n, sig[0]) and all(np.array_equal(ref[1][b, :n[b]], sig[1][b, :n[b]]) and
                                                       np.array_equal(ref[2][b, :n[b]], sig[2][b, :n[b]]) for b in range(B))
             print("variant %d output identical to variant %d: %s" % (v, variants[0], same), file=sys.stderr)
     for r in range(args.rounds):
         for v in variants:
-            L.orbhip_dev_set_fast_variant(ext._h, v)
+            select(v)
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
