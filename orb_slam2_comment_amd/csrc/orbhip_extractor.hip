@@ -79,6 +79,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh, int *total)
 __device__ __forceinline__ int block_excl_scan256(int v, int *sh, int *total) { return block_excl_scan<256>(v, sh, total); }
 
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
 {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b), c, false);
@@ -269,16 +270,22 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
             __builtin_memcpy(&w0[r], sroi + (uint32_t)__mul24((int)yt[r].x, P.pitch) + lo, 8);
             __builtin_memcpy(&w1[r], sroi + (uint32_t)__mul24((int)yt[r].y, P.pitch) + lo, 8);
         }
-        const int rel[4] = {sxk[0] - lo, sxk[1] - lo, sxk[2] - lo, sxk[3] - lo};
+        // v_perm_b32 selector of tap k: bytes (rel, rel + 1) of the 8-byte window, zero-extended to two uint16 lanes
+        uint32_t sel[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t rel = (uint32_t)(sxk[k] - lo);
+            sel[k] = 0x0c000c00u | rel | ((rel + 1u) << 16);
+        }
 #pragma unroll
         for (int r = 0; r < kPyrRows; ++r) {
             const int b0 = yt[r].z, b1 = yt[r].w;
+            const uint32_t w0l = (uint32_t)w0[r], w0h = (uint32_t)(w0[r] >> 32), w1l = (uint32_t)w1[r], w1h = (uint32_t)(w1[r] >> 32);
             uint32_t acc = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t q0 = (uint32_t)(w0[r] >> (8 * rel[k])), q1 = (uint32_t)(w1[r] >> (8 * rel[k]));
-                const uint32_t h0 = udot2(__builtin_amdgcn_perm(0u, q0, 0x0c010c00u), alv[k], 0);
-                const uint32_t h1 = udot2(__builtin_amdgcn_perm(0u, q1, 0x0c010c00u), alv[k], 0);
+                const uint32_t h0 = udot2(__builtin_amdgcn_perm(w0h, w0l, sel[k]), alv[k], 0);
+                const uint32_t h1 = udot2(__builtin_amdgcn_perm(w1h, w1l, sel[k]), alv[k], 0);
                 // b <= 2048 and h >> 4 < 2^15: the 24-bit multiplier is exact and full rate (v_mul_lo_u32 is quarter rate)
                 const uint32_t v = (uint32_t)(((__mul24(b0, (int)(h0 >> 4)) >> 16) + (__mul24(b1, (int)(h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
                 acc |= v << (8 * k);
@@ -1089,83 +1096,137 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 
 // ---------------------------------------------------------------------------
 // K5+K7: IC_Angle (:77-104) + steered rBRIEF (:108-147) + output assembly
-// (:1095-1103), one wavefront per keypoint.  Moments: the 749 disc pixels are
-// spread over the 64 lanes and reduced with shuffles.  Descriptor: test t = 64*j+lane,
-// so four 64-bit ballots are the 32 descriptor bytes (LSB-first) directly.
+// (:1095-1103), one wavefront per keypoint (4 per workgroup, no workgroup barrier).
+//  * everything that depends only on the slot (level, output index, plane base) is wave-uniform and
+//    computed on the scalar unit;
+//  * moments: the 749 disc pixels are spread over the 64 lanes, 12 per lane; their byte offsets come from
+//    a host-built per-level table (v * pitch + u), the (u, v) weights as int16 pairs, so a pair of pixels
+//    costs one pack + two v_dot2_i32_i16; shuffle reduction;
+//  * the 37 x 40-byte blurred patch the descriptor samples (|rotated offset| <= 18) is fetched in the SAME
+//    memory round trip as the disc pixels (its address does not depend on the angle) into this wavefront's
+//    LDS tile: lane = (row mod 6, dword column), 7 loads per lane;
+//  * descriptor: test t = 64*j + lane with the pattern as a float4 table (x0, y0, x1, y1), so four 64-bit
+//    ballots are the 32 descriptor bytes (LSB-first) directly.
 // ---------------------------------------------------------------------------
+constexpr int kPatchDw = 10;     // dwords per staged patch row: 37 bytes starting at most 3 bytes into the first dword
+constexpr int kPatchRows = 37;
+constexpr int kPatchRpi = 6;     // rows per staging instruction (60 of 64 lanes)
+constexpr int kDescPerWave = 2;  // consecutive keypoint slots per wavefront (1: 65 us, 2: 60 us, 4: 65 us, 8: 88 us per 64 frames)
+constexpr int kDiscDw = 9;       // dwords per staged row of the 31 x 31 orientation window (31 bytes starting <= 3 bytes in)
+constexpr int kDiscRows = 31;
+constexpr int kDiscRpi = 7;      // rows per staging instruction (63 of 64 lanes)
 
 __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restrict__ pyr,
                                                          const uint8_t *__restrict__ blur, PyrGeom G,
                                                          const uint32_t *__restrict__ sel_kp,
                                                          const int *__restrict__ sel_cnt,
                                                          const DiscTab *__restrict__ disc,
-                                                         const int *__restrict__ pattern,
+                                                         const int *__restrict__ disc_off,
+                                                         const float4 *__restrict__ patternf,
                                                          orbhip_keypoint *__restrict__ out_kp,
                                                          uint8_t *__restrict__ out_desc, int cap,
-                                                         int *__restrict__ out_n, int *__restrict__ status)
+                                                         int *__restrict__ out_n, int *__restrict__ status, int per_wave)
 {
+    __shared__ uint32_t spatch[4][kPatchRows * kPatchDw + 8];
+    __shared__ uint32_t sdisc[4][kDiscRows * kDiscDw + 8];
     const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bx, b;
     xcd_remap(bx, b);
-    const int slot = bx * 4 + (threadIdx.x >> 6);
-    if (slot >= G.kp_cap_total) return;
-    // keypoint-independent operands first, so that their latency overlaps the slot lookup:
-    // this lane's 12 disc offsets (u | v << 8, zero padded) and its 4 rBRIEF test pairs
-    unsigned short duv[12];
+    // per-lane constants of the whole kernel stay in registers across the kDescPerWave keypoints of this wavefront:
+    // the (u, v) weights of its 12 disc pixels and its 4 rBRIEF test pairs; the byte offsets of the disc pixels
+    // depend on the level's pitch and are reloaded when the level changes (slots are level-major: rarely)
+    uint32_t u2[6], v2[6];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) duv[i] = disc->uv[i * 64 + lane];
-    int pat[4];
+    for (int k = 0; k < 6; ++k) { u2[k] = disc->u2[k * 64 + lane]; v2[k] = disc->v2[k * 64 + lane]; }
+    float4 pat[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) pat[j] = pattern[j * 64 + lane];
-    int level = 0;
-    for (int l = 1; l < G.nlevels; ++l) if (slot >= G.lv[l].kp_base) level = l;
-    const LevelGeom L = G.lv[level];
-    const int i = slot - L.kp_base;
+    for (int j = 0; j < 4; ++j) pat[j] = patternf[j * 64 + lane];
+    int dl[12];   // byte offset of this lane's 12 disc pixels inside the staged 31-row tile: (v + 15) * 36 + (u + 15)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) dl[k] = disc_off[k * 64 + lane];
     const int *cnts = sel_cnt + b * ORBHIP_MAX_LEVELS;
-    int before = 0, total = 0;
-    for (int l = 0; l < G.nlevels; ++l) { int c = cnts[l]; if (l < level) before += c; total += c; }
-    if (slot == 0 && lane == 0) {
+    int total = 0;
+    for (int l = 0; l < G.nlevels; ++l) total += cnts[l];
+    if (bx == 0 && wv == 0 && lane == 0) {
         out_n[b] = min(total, cap);
         if (total > cap && status) atomicExch(&status[b], ORBHIP_E_CAPACITY);
     }
-    if (i >= cnts[level]) return;
+    const int prow = lane / kPatchDw, pcol = lane - prow * kPatchDw;   // patch staging: lanes 60..63 idle
+    const int drow = lane / kDiscDw, dcol = lane - drow * kDiscDw;     // disc staging: lane 63 idle
+    uint32_t *patch = spatch[wv];
+    uint32_t *dtile = sdisc[wv];
+  for (int kk = 0; kk < per_wave; ++kk) {
+    const int slot = (bx * 4 + wv) * per_wave + kk;  // wave-uniform: everything up to the pixel loads is scalar work
+    if (slot >= G.kp_cap_total) break;
+    int level = 0;
+    for (int l = 1; l < G.nlevels; ++l) if (slot >= G.lv[l].kp_base) level = l;
+    int before = 0, mine = 0;
+    for (int l = 0; l < G.nlevels; ++l) {
+        const int c = cnts[l];
+        if (l < level) before += c;
+        if (l == level) mine = c;
+    }
+    const int kp_base = G.lv[level].kp_base, pitch = G.lv[level].pitch;
+    const int i = slot - kp_base;
+    if (i >= mine) continue;
     const int oidx = before + i;
-    if (oidx >= cap) return;
+    if (oidx >= cap) continue;
 
     const uint32_t kv = sel_kp[(size_t)b * G.kp_cap_total + slot];
     const int kx = (int)(kv & 0xfff) + 16, ky = (int)((kv >> 12) & 0xfff) + 16;  // + minBorder (:843-844)
     const int resp = (int)(kv >> 24);
-    const size_t fo = (size_t)b * G.frame_bytes + L.plane_off + (size_t)kEdge * L.pitch + kPadL;
-    const uint8_t *c = pyr + fo + (size_t)ky * L.pitch + kx;
-
-    // The 37x37 blurred patch the descriptor samples (|rotated offset| <= 18) is fetched NOW, as aligned dwords, into
-    // this wavefront's LDS tile, together with the 12 disc pixels: one memory round trip instead of two (the taps'
-    // addresses depend on the angle, the patch does not).
-    __shared__ uint32_t spatch[4][37 * 11];
-    uint32_t *patch = spatch[threadIdx.x >> 6];
-    const int xs = (kx - 18) & ~3;                       // dword-aligned ROI column of patch column 0
-    const uint8_t *bb = blur + fo + (size_t)(ky - 18) * L.pitch + xs;
+    const size_t fo = (size_t)b * G.frame_bytes + G.lv[level].plane_off + (size_t)kEdge * pitch + kPadL;
+    const uint8_t *c = pyr + fo + (size_t)ky * pitch + kx;          // keypoint in the unblurred level (uniform)
+    // ---- issue every load of the round trip: the 31-row disc window of the unblurred level and the blurred patch,
+    // both as aligned dwords (lane = (row mod R, dword column)); the per-pixel reads then come from LDS ----
+    const int xd = (kx - 15) & ~3;                                  // dword-aligned ROI column of disc-tile column 0
+    const uint8_t *db = c - (size_t)15 * pitch - (kx - xd);
+    uint32_t dv[5];
+    {
+        const uint32_t voff = (uint32_t)(__mul24(drow, pitch) + 4 * dcol);
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+            dv[u] = (lane < kDiscRpi * kDiscDw) ? *reinterpret_cast<const uint32_t *>(db + (uint32_t)(u * kDiscRpi * pitch) + voff) : 0u;
+    }
+    const int xs = (kx - 18) & ~3;                                  // dword-aligned ROI column of patch column 0
+    const uint8_t *bb = blur + fo + (size_t)(ky - 18) * pitch + xs;
     uint32_t pv[7];
+    {
+        const uint32_t voff = (uint32_t)(__mul24(prow, pitch) + 4 * pcol);
 #pragma unroll
-    for (int u = 0; u < 7; ++u) {
-        const int idx = min(u * 64 + lane, 37 * 11 - 1);
-        const int r = (idx * 5958) >> 16, cdw = idx - r * 11;   // idx / 11 for idx < 407
-        pv[u] = *reinterpret_cast<const uint32_t *>(bb + (uint32_t)(__mul24(r, L.pitch) + 4 * cdw));   // 24-bit operands: full-rate multiplier
+        for (int u = 0; u < 7; ++u)
+            pv[u] = (lane < kPatchRpi * kPatchDw) ? *reinterpret_cast<const uint32_t *>(bb + (uint32_t)(u * kPatchRpi * pitch) + voff) : 0u;
     }
+    __builtin_amdgcn_wave_barrier();                     // the previous keypoint's LDS reads are done
+    {
+        uint32_t *dd = dtile + (drow * kDiscDw + dcol);
+        if (lane < kDiscRpi * kDiscDw) {
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+                if (u < 4 || drow < kDiscRows - 4 * kDiscRpi) dd[u * kDiscRpi * kDiscDw] = dv[u];   // rows 28..34: only 28..30 exist
+        }
+        uint32_t *pd = patch + (prow * kPatchDw + pcol);
+        if (lane < kPatchRpi * kPatchDw) {
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                if (u < 6 || prow == 0) pd[u * kPatchRpi * kPatchDw] = pv[u];    // rows 36..41: only row 36 exists
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- moments ----
     int m10 = 0, m01 = 0;
-    int pix[12];
+    {
+        const uint8_t *d8 = reinterpret_cast<const uint8_t *>(dtile) + (kx - 15 - xd);
+        int pix[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int u = (signed char)(duv[i] & 0xff), v = (signed char)(duv[i] >> 8);
-        pix[i] = c[__mul24(v, L.pitch) + u];
-    }
+        for (int k = 0; k < 12; ++k) pix[k] = d8[dl[k]];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) patch[min(u * 64 + lane, 37 * 11 - 1)] = pv[u];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int u = (signed char)(duv[i] & 0xff), v = (signed char)(duv[i] >> 8);
-        m10 += __mul24(u, pix[i]);
-        m01 += __mul24(v, pix[i]);
+        for (int k = 0; k < 6; ++k) {
+            const uint32_t p2 = (uint32_t)pix[2 * k] | ((uint32_t)pix[2 * k + 1] << 16);
+            m10 = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, p2), __builtin_bit_cast(i16x2_t, u2[k]), m10, false);
+            m01 = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, p2), __builtin_bit_cast(i16x2_t, v2[k]), m01, false);
+        }
     }
     m10 = wave_reduce_add(m10);
     m01 = wave_reduce_add(m01);
@@ -1175,20 +1236,18 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
     float a, bsn;
     det_sincos(__fmul_rn(angle, factorPI), &a, &bsn);
     __builtin_amdgcn_wave_barrier();                     // the tile is private to this wavefront; DS ops are in order
-    const uint8_t *cb = reinterpret_cast<const uint8_t *>(patch) + 18 * 44 + (kx - xs);   // patch byte of the keypoint
+    const uint8_t *cb = reinterpret_cast<const uint8_t *>(patch) + 18 * (kPatchDw * 4) + (kx - xs);   // patch byte of the keypoint
     unsigned long long bits[4];
     int t0v[4], t1v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int pw = pat[j];
-        const float px0 = (float)(signed char)(pw & 0xff), py0 = (float)(signed char)((pw >> 8) & 0xff);
-        const float px1 = (float)(signed char)((pw >> 16) & 0xff), py1 = (float)(signed char)((pw >> 24) & 0xff);
+        const float px0 = pat[j].x, py0 = pat[j].y, px1 = pat[j].z, py1 = pat[j].w;
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, bsn), __fmul_rn(py0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, bsn)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, bsn), __fmul_rn(py1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, bsn)));
-        t0v[j] = cb[__mul24(r0, 44) + c0];
-        t1v[j] = cb[__mul24(r1, 44) + c1];
+        t0v[j] = cb[__mul24(r0, kPatchDw * 4) + c0];
+        t1v[j] = cb[__mul24(r1, kPatchDw * 4) + c1];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) bits[j] = __ballot(t0v[j] < t1v[j]);
@@ -1199,11 +1258,13 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
     if (lane == 0) {
         orbhip_keypoint kp;
         float fx = (float)kx, fy = (float)ky;
-        if (level != 0) { fx = __fmul_rn(fx, L.scale); fy = __fmul_rn(fy, L.scale); }
-        kp.x = fx; kp.y = fy; kp.size = (float)L.patch; kp.angle = angle; kp.response = (float)resp;
+        const float scale = G.lv[level].scale;
+        if (level != 0) { fx = __fmul_rn(fx, scale); fy = __fmul_rn(fy, scale); }
+        kp.x = fx; kp.y = fy; kp.size = (float)G.lv[level].patch; kp.angle = angle; kp.response = (float)resp;
         kp.octave = level; kp.class_id = -1;
         out_kp[(size_t)b * cap + oidx] = kp;
     }
+  }
 }
 
 __global__ void k_zero_status(int *status, int n)
@@ -1424,15 +1485,18 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
     e->fast_params.frame_bytes = G.frame_bytes; e->fast_params.ncells_total = G.ncells_total; e->fast_params.slot_cap = G.slot_cap;
     if (!e->cells.empty()) {
         ORBHIP_HIP_CHECK(hipMalloc(&e->d_cells, e->cells.size() * sizeof(CellDesc)));
-        ORBHIP_HIP_CHECK(hipMemcpy(e->d_cells, e->cells.data(), e->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_cells, e->cells.data(), e->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice, e->stream));
         ORBHIP_HIP_CHECK(hipMalloc(&e->d_cells2, e->cells2.size() * sizeof(FastCell)));
-        ORBHIP_HIP_CHECK(hipMemcpy(e->d_cells2, e->cells2.data(), e->cells2.size() * sizeof(FastCell), hipMemcpyHostToDevice));
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_cells2, e->cells2.data(), e->cells2.size() * sizeof(FastCell), hipMemcpyHostToDevice, e->stream));
     }
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_tiles, e->tiles.size() * sizeof(TileDesc)));
-    ORBHIP_HIP_CHECK(hipMemcpy(e->d_tiles, e->tiles.data(), e->tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_tiles, e->tiles.data(), e->tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, e->stream));
     if (tabs.empty()) tabs.push_back(0);
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_tabs, tabs.size() * sizeof(short)));
-    ORBHIP_HIP_CHECK(hipMemcpy(e->d_tabs, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_tabs, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice, e->stream));
+    // uploads go through the handle's own stream (a legacy-stream hipMemcpy would tangle with another host thread's
+    // stream capture: the stereo constructor runs two extractors on two threads); the host vectors die at return
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
     e->bound = true;
     return ORBHIP_OK;
 }
@@ -1531,8 +1595,12 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, b_pyr, b_blur, G,
                        e->d_tiles, e->blurw);
     if (prof) (void)hipEventRecord(ev[4], s);
-    hipLaunchKernelGGL(k_orient_describe, dim3((G.kp_cap_total + 3) / 4, batch), dim3(256), 0, s, b_pyr, b_blur,
-                       G, b_sel, b_sel_cnt, e->d_disc, e->d_pattern, d_kps, d_desc, cap, d_n, status);
+    {
+        static const int dev_pw = getenv("ORBHIP_DESC_PER_WAVE") ? atoi(getenv("ORBHIP_DESC_PER_WAVE")) : 0;
+        const int pw = dev_pw > 0 ? dev_pw : kDescPerWave;
+        hipLaunchKernelGGL(k_orient_describe, dim3((G.kp_cap_total + 4 * pw - 1) / (4 * pw), batch), dim3(256), 0, s, b_pyr, b_blur,
+                           G, b_sel, b_sel_cnt, e->d_disc, e->d_disc_off, e->d_patternf, d_kps, d_desc, cap, d_n, status, pw);
+    }
     if (prof) { (void)hipEventRecord(ev[5], s); e->prof_calls++; }
     e->last_batch = frame0 + batch;
     ORBHIP_HIP_CHECK(hipGetLastError());
@@ -1593,21 +1661,38 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
         return ORBHIP_E_HIP;
     }
     e->stream = e->own_stream;
-    // disc offsets in the reference's traversal order (order is irrelevant for integer sums)
-    DiscTab dt; memset(&dt, 0, sizeof(dt));   // padding entries (u = v = 0) contribute 0 to both moments
+    // disc offsets in the reference's traversal order (order is irrelevant for integer sums): pixel k of lane l is entry
+    // k*64 + l; padding entries (u = v = 0) re-read the centre pixel with weight 0
+    DiscTab &dt = e->disc_host; memset(&dt, 0, sizeof(dt));
     int nd = 0;
-    auto put = [&](int u, int v) { dt.uv[nd++] = (unsigned short)((u & 0xff) | ((v & 0xff) << 8)); };
+    signed char du[768], dv[768];
+    memset(du, 0, sizeof(du)); memset(dv, 0, sizeof(dv));
+    auto put = [&](int u, int v) { du[nd] = (signed char)u; dv[nd] = (signed char)v; ++nd; };
     for (int u = -kHalfPatch; u <= kHalfPatch; ++u) put(u, 0);
     for (int vv = 1; vv <= kHalfPatch; ++vv) {
         int d = e->umax[vv];
         for (int u = -d; u <= d; ++u) { put(u, vv); put(u, -vv); }
     }
     if (nd != 749) { set_error("disc table has %d entries", nd); orbhip_extractor_destroy(e); return ORBHIP_E_ARG; }
-    if (hipMalloc(&e->d_disc, sizeof(DiscTab)) != hipSuccess || hipMalloc(&e->d_pattern, 256 * sizeof(int)) != hipSuccess) {
+    for (int k = 0; k < 12; ++k)
+        for (int l = 0; l < 64; ++l) { dt.u[k * 64 + l] = du[k * 64 + l]; dt.v[k * 64 + l] = dv[k * 64 + l]; }
+    for (int k = 0; k < 6; ++k)
+        for (int l = 0; l < 64; ++l) {   // int16 pairs (pixel 2k, pixel 2k+1) of lane l
+            dt.u2[k * 64 + l] = (uint32_t)(uint16_t)(short)du[(2 * k) * 64 + l] | ((uint32_t)(uint16_t)(short)du[(2 * k + 1) * 64 + l] << 16);
+            dt.v2[k * 64 + l] = (uint32_t)(uint16_t)(short)dv[(2 * k) * 64 + l] | ((uint32_t)(uint16_t)(short)dv[(2 * k + 1) * 64 + l] << 16);
+        }
+    float patf[1024];
+    for (int t = 0; t < 1024; ++t) patf[t] = (float)orbhip_rbrief_pattern[t];
+    if (hipMalloc(&e->d_disc, sizeof(DiscTab)) != hipSuccess || hipMalloc(&e->d_patternf, sizeof(patf)) != hipSuccess ||
+        hipMalloc(&e->d_disc_off, 768 * sizeof(int)) != hipSuccess) {
         set_error("hipMalloc failed"); orbhip_extractor_destroy(e); return ORBHIP_E_HIP;
     }
-    if (hipMemcpy(e->d_disc, &dt, sizeof(dt), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(e->d_pattern, orbhip_rbrief_pattern, 1024, hipMemcpyHostToDevice) != hipSuccess) {
+    int dloff[768];   // byte offset of every disc pixel inside the staged 31 x 36-byte tile; padding entries read (0, 0) with weight 0
+    for (int t = 0; t < 768; ++t) dloff[t] = ((int)dv[t] + kHalfPatch) * 36 + ((int)du[t] + kHalfPatch);
+    if (hipMemcpyAsync(e->d_disc_off, dloff, sizeof(dloff), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipMemcpyAsync(e->d_disc, &dt, sizeof(dt), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipMemcpyAsync(e->d_patternf, patf, sizeof(patf), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess) {
         set_error("upload of the orientation / rBRIEF tables failed"); orbhip_extractor_destroy(e); return ORBHIP_E_HIP;
     }
     *out = e;
@@ -1621,7 +1706,7 @@ void orbhip_extractor_destroy(orbhip_extractor *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_geometry(e);
     free_batch(e);
-    (void)hipFree(e->d_disc); (void)hipFree(e->d_pattern); (void)hipFree(e->d_img); (void)hipFree(e->d_okp); (void)hipFree(e->d_odesc); (void)hipFree(e->d_on);
+    (void)hipFree(e->d_disc); (void)hipFree(e->d_patternf); (void)hipFree(e->d_disc_off); (void)hipFree(e->d_img); (void)hipFree(e->d_okp); (void)hipFree(e->d_odesc); (void)hipFree(e->d_on);
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     for (hipEvent_t v : e->ev) (void)hipEventDestroy(v);

@@ -29,7 +29,9 @@ struct FastParams {
     int ncells_total, slot_cap, ini_th, min_th, img_words, score_words;
     int dev;   // development switch (timing floors)
 };
-struct DiscTab { unsigned short uv[768]; };  // 749 disc offsets (u | v << 8), zero padded to 12 x 64
+// the 749 disc offsets of IC_Angle, zero padded to 12 x 64 (pixel k of lane l = entry k*64 + l): signed (u, v) and the
+// int16 pairs (pixel 2k | pixel 2k+1 << 16) the moment dot products take
+struct DiscTab { signed char u[768], v[768]; uint32_t u2[384], v2[384]; };
 }  // namespace orbhip
 
 struct orbhip_extractor {
@@ -66,7 +68,9 @@ struct orbhip_extractor {
     orbhip::TileDesc *d_tiles = nullptr;
     short *d_tabs = nullptr;
     orbhip::DiscTab *d_disc = nullptr;
-    int *d_pattern = nullptr;
+    orbhip::DiscTab disc_host;
+    int *d_disc_off = nullptr;      // [768] byte offsets of the disc pixels inside the staged 31 x 36-byte LDS tile
+    float4 *d_patternf = nullptr;   // rBRIEF pattern as floats: (x0, y0, x1, y1) per test
 
     // per-batch-capacity buffers
     int batch_cap = 0;

@@ -930,6 +930,7 @@ __device__ __forceinline__ void resolve_par_carve(ResolveParState &S, unsigned c
     S.t_oct = c; c += n; S.taken = c; c += n; S.q_obs = c; c += nq; S.evbin = c;
 }
 
+__device__ unsigned int g_resolve_stats[4];   // development: {launched workgroups, sum of rounds, max rounds, -}
 template <bool GS>
 __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, const orbhip_query *__restrict__ q, int nq,
                                                       const unsigned long long *__restrict__ cand,
@@ -958,8 +959,11 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     ResolveParState S;
     if (GS) resolve_par_carve(S, gstate + (size_t)blockIdx.x * gstate_stride, (size_t)n, (size_t)nq);
     else resolve_par_carve(S, resolve_lds, kResolveMax, kResolveMax);
+    // ping-pong owner arrays as two named pointers that swap every round (indexing S.owner[] with a run-time value would
+    // put the whole state struct into scratch memory)
+    int *own_cur = S.owner[0], *own_nxt = S.owner[1];
     for (int i = tid; i < n; i += T) {
-        S.owner[0][i] = INT_MAX;
+        own_cur[i] = INT_MAX;
         S.taken[i] = (unsigned char)(taken_in ? taken_in[i] != 0 : 0);
         S.t_angle[i] = F.keys[i].angle;
         S.t_oct[i] = (unsigned char)F.keys[i].octave;
@@ -986,10 +990,9 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
             for (int e = 0; e < kHead; ++e) head[e] = e < head_c ? l0[e] : ~0ull;
         }
     }
-    int cur = 0;
     for (int round = 0; round <= nq + 1; ++round) {
         if (tid == 0) S.vars[0] = 0;
-        for (int c = tid; c < n; c += T) S.owner[cur ^ 1][c] = INT_MAX;
+        for (int c = tid; c < n; c += T) own_nxt[c] = INT_MAX;
         __syncthreads();
         for (int i = tid; i < nq; i += T) {
             const int c = i == tid ? head_c : cnt[i];
@@ -1003,7 +1006,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                         if (i == tid && e < kHead) v = e == 0 ? head[0] : e == 1 ? head[1] : e == 2 ? head[2] : head[3];
                         else v = list[e];
                         const int idx = (int)(v & 0xfffffu);
-                        if (S.taken[idx] || S.owner[cur][idx] < i) continue;
+                        if (S.taken[idx] || own_cur[idx] < i) continue;
                         if (k1 == ~0ull) { k1 = v; if (mode == 0 || mode == 4) break; }
                         else { k2 = v; break; }
                     }
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                     for (int e = 0; e < -c; ++e) {
                         const unsigned long long v = list[e];
                         const int idx = (int)(v & 0xfffffu);
-                        if (S.taken[idx] || S.owner[cur][idx] < i) continue;
+                        if (S.taken[idx] || own_cur[idx] < i) continue;
                         if (v < k1) { k2 = k1; k1 = v; } else if (v < k2) k2 = v;
                     }
                 }
@@ -1028,16 +1031,19 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                 }
             }
             if (newc != S.choice[i]) { S.choice[i] = newc; S.vars[0] = 1; }
-            if (newc >= 0 && S.q_obs[i]) atomicMin(&S.owner[cur ^ 1][newc], i);
+            if (newc >= 0 && S.q_obs[i]) atomicMin(&own_nxt[newc], i);
         }
         __syncthreads();
-        cur ^= 1;
+        { int *t_ = own_cur; own_cur = own_nxt; own_nxt = t_; }
         const int changed = S.vars[0];
         __syncthreads();
-        if (!changed) break;
+        if (!changed) {
+            if (tid == 0) { atomicAdd(&g_resolve_stats[0], 1u); atomicAdd(&g_resolve_stats[1], (unsigned)round + 1); atomicMax(&g_resolve_stats[2], (unsigned)round + 1); }
+            break;
+        }
     }
     // ---- outputs: assign[slot] = last accepted query that picked it; rotation-histogram cull (mode 0) ----
-    int *assign = S.owner[cur ^ 1];   // reuse
+    int *assign = own_nxt;   // reuse
     for (int c = tid; c < n; c += T) assign[c] = -1;
     __syncthreads();
     int acc_local = 0;
@@ -1795,8 +1801,10 @@ static int launch_resolve_par(orbhip_matcher *m, int pairs, int mode, const DevF
                               const uint8_t *d_taken, float nnratio, int check_ori, int *d_out, int *d_out_n, const Batch &B,
                               int th_accept, int all_block)
 {
+    static const int dev_threads = getenv("ORBHIP_RESOLVE_THREADS") ? atoi(getenv("ORBHIP_RESOLVE_THREADS")) : 0;
+    const int threads = dev_threads ? dev_threads : 1024;
     if (n_train <= kResolveMax && nq <= kResolveMax) {
-        hipLaunchKernelGGL(k_resolve_par<false>, dim3(pairs), dim3(1024), resolve_par_bytes(kResolveMax, kResolveMax), m->stream,
+        hipLaunchKernelGGL(k_resolve_par<false>, dim3(pairs), dim3(threads), resolve_par_bytes(kResolveMax, kResolveMax), m->stream,
                            mode, D, d_q, nq, d_cand, d_ccand, d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out_n, B, th_accept,
                            all_block, (unsigned char *)nullptr, (size_t)0);
     } else {
@@ -2760,6 +2768,15 @@ int orbhip_frustum_queries(orbhip_matcher *m, const orbhip_camera *cam, const fl
     ORBHIP_HIP_CHECK(hipMemcpyAsync(q, p, (size_t)n * sizeof(orbhip_query), hipMemcpyDeviceToHost, m->stream));
     if (view_cos) ORBHIP_HIP_CHECK(hipMemcpyAsync(view_cos, pv, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBHIP_OK;
+}
+
+// development: {workgroups, sum of rounds, max rounds} of the parallel resolve since the last call
+int orbhip_dev_resolve_stats(unsigned int out[4])
+{
+    unsigned int z[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(orbhip::g_resolve_stats), sizeof(z)) != hipSuccess) return ORBHIP_E_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(orbhip::g_resolve_stats), z, sizeof(z)) != hipSuccess) return ORBHIP_E_HIP;
     return ORBHIP_OK;
 }
 
