@@ -164,7 +164,7 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def timed(fn, sync, steps, min_s=MIN_TIMED_S, allreduce_max=None):
+def timed(fn, sync, steps, min_s, allreduce_max=None):
     """Run `steps` calls of fn R times so that the timed region lasts >= min_s; returns (seconds, R)."""
     sync()
     t0 = time.perf_counter()
@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-gpu", type=int, default=128,
                     help="frames resident in HBM per GPU and step (two 64-frame pipelines by default)")
+    ap.add_argument("--min-time", type=float, default=MIN_TIMED_S,
+                    help="minimum length in seconds of every timed region (profiler runs pass 0: one repeat of --steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", "--no-match", dest="no_secondary", action="store_true",
                     help="skip the secondary legs (extract-only, stereo, EuRoC initialisation, BoW)")
@@ -410,7 +412,7 @@ def main():
     for e in exts:
         e.set_profiling(True)                   # HIP events around every stage, on the launch stream
     record_match[0] = True
-    reps = max(1, int(np.ceil(MIN_TIMED_S / max(dt_k, 1e-6))))
+    reps = max(1, int(np.ceil(args.min_time / max(dt_k, 1e-6))))
     reps = int(allreduce_max(float(reps)))
     barrier()
     t0 = time.perf_counter()
@@ -527,7 +529,7 @@ def secondary_legs(args, torch, dev, local_rank, exts, streams, o, d_img, cap, s
     def leg(fn, steps):
         for _ in range(3):
             fn()
-        return timed(fn, sync, steps)
+        return timed(fn, sync, steps, args.min_time)
 
     # ---- configs[1]: extract-only ------------------------------------------------------------------------------
     for e in exts:

@@ -41,7 +41,6 @@ struct LevelGeom {
     int quota;             // mnFeaturesPerLevel[level]
     int kp_base, kp_cap;   // slice of the per-frame selected-keypoint array
     int cand_base, cand_cap; // slice of the per-frame octree key workspace
-    int xtab, atab, ytab;  // offsets (in int16 units, 16-B aligned) of the resize tables: sx[w], {a0,a1}[w], {sy0,sy1,b0,b1}[h]
     int patch;             // scaledPatchSize, :837
     float scale;           // mvScaleFactor[level]
 };

@@ -199,12 +199,11 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ 
     }
 }
 
-// Resize tables (host-built, OpenCV fixed-point): per destination column sx[x] and the
-// coefficient pair {alpha0, alpha1}, per destination row {sy0, sy1, beta0, beta1}, all int16.
-// Interior groups of 4 destination pixels take the fast path: the <= 6 source bytes of each of
-// the two source rows are fetched with three aligned dword loads, re-aligned with
-// v_alignbyte_b32, and the horizontal taps are v_dot2_u32_u16; groups that touch the
-// REFLECT_101 border recompute the reflected interior pixel byte by byte.
+// resize(INTER_LINEAR, 8U) in OpenCV's fixed-point arithmetic.  A thread derives the source column / row and the
+// Q11 coefficient pair of each of its 4 destination columns and 4 rows in registers (resize_coef).  Groups whose four
+// taps fit one 8-byte source window (always, for scale factors <= 2.3) take the fast path: one byte-aligned 8-byte
+// load per source row, taps picked with v_perm_b32, horizontal filter v_dot2_u32_u16; groups that touch the
+// REFLECT_101 border revisit the reflected interior columns through the same path.
 __device__ __forceinline__ uint32_t resize_px(const uint8_t *S0, const uint8_t *S1, int sx, int a0, int a1, int b0, int b1)
 {
     // sx+1 may be the first border byte when sx == sw-1; a1 is 0 there.
@@ -215,8 +214,30 @@ __device__ __forceinline__ uint32_t resize_px(const uint8_t *S0, const uint8_t *
 
 constexpr int kPyrRows = 4;   // destination rows per thread (independent loads in flight)
 
-__global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, PyrGeom G, int level,
-                                                    const short *__restrict__ tabs)
+// OpenCV's fixed-point bilinear coefficients of one destination coordinate d (resize INTER_LINEAR, 8U):
+// f = (float)((d + 0.5) * scale - 0.5) in double, s = floor(f), f -= s, clamped at the ends; coefficients
+// cvRound((1 - f) * 2048), cvRound(f * 2048).  Same operations as the host-built tables (bind_geometry), so a
+// thread can derive its coefficients in registers instead of waiting for a table load before it can address
+// its source pixels.
+__device__ __forceinline__ void resize_coef(int d, double scale, int slen, bool clamp_both, int &s0, int &s1, int &c0, int &c1)
+{
+    float f = (float)__dsub_rn(__dmul_rn(__dadd_rn((double)d, 0.5), scale), 0.5);
+    int s = (int)floorf(f);
+    f = __fsub_rn(f, (float)s);
+    if (clamp_both) {      // rows: both taps clamped independently, the fraction is kept
+        s0 = s < 0 ? 0 : (s < slen ? s : slen - 1);
+        s1 = s + 1 < 0 ? 0 : (s + 1 < slen ? s + 1 : slen - 1);
+    } else {               // columns: the fraction is dropped at the ends
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= slen - 1) { f = 0.f; s = slen - 1; }
+        s0 = s; s1 = s + 1;
+    }
+    c0 = __float2int_rn(__fmul_rn(__fsub_rn(1.f, f), 2048.f));
+    c1 = __float2int_rn(__fmul_rn(f, 2048.f));
+}
+struct ResizeScale { double sx, sy; };
+
+__global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, PyrGeom G, int level, ResizeScale RS)
 {
     const LevelGeom L = G.lv[level];
     const LevelGeom P = G.lv[level - 1];
@@ -237,21 +258,14 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
     uint32_t alv[4];
     uint32_t vmask = 0;
     const bool interior = x0 >= 0 && x0 + 3 < L.w;
-    if (interior) {
-        const short4 sx = *reinterpret_cast<const short4 *>(tabs + L.xtab + x0);
-        const uint4 al = *reinterpret_cast<const uint4 *>(tabs + L.atab + 2 * x0);   // a0 | a1 << 16 per pixel
-        sxk[0] = sx.x; sxk[1] = sx.y; sxk[2] = sx.z; sxk[3] = sx.w;
-        alv[0] = al.x; alv[1] = al.y; alv[2] = al.z; alv[3] = al.w;
-        vmask = 0xffffffffu;
-    } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int x = x0 + k;
-            if (x >= -kEdge && x < L.w + kEdge) vmask |= 0xffu << (8 * k);
-            const int dx = reflect101(min(max(x, -kEdge), L.w + kEdge - 1), L.w);
-            sxk[k] = tabs[L.xtab + dx];
-            alv[k] = *reinterpret_cast<const uint32_t *>(tabs + L.atab + 2 * dx);
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int x = x0 + k;
+        if (x >= -kEdge && x < L.w + kEdge) vmask |= 0xffu << (8 * k);
+        const int dx = interior ? x : reflect101(min(max(x, -kEdge), L.w + kEdge - 1), L.w);
+        int s1, a0, a1;
+        resize_coef(dx, RS.sx, P.w, false, sxk[k], s1, a0, a1);
+        alv[k] = (uint32_t)a0 | ((uint32_t)a1 << 16);
     }
     const int lo = min(min(sxk[0], sxk[1]), min(sxk[2], sxk[3]));
     const int hi = max(max(sxk[0], sxk[1]), max(sxk[2], sxk[3]));
@@ -259,7 +273,9 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
 #pragma unroll
     for (int r = 0; r < kPyrRows; ++r) {
         const int py = min(rq * kPyrRows + r, L.prows - 1);
-        yt[r] = *reinterpret_cast<const short4 *>(tabs + L.ytab + 4 * reflect101(py - kEdge, L.h));
+        int s0, s1, b0, b1;
+        resize_coef(reflect101(py - kEdge, L.h), RS.sy, P.h, true, s0, s1, b0, b1);
+        yt[r] = make_short4((short)s0, (short)s1, (short)b0, (short)b1);
     }
     uint32_t out[kPyrRows];
     if (hi - lo <= 6) {   // the 8-byte source window covers all four taps (scale factors <= 2.3)
@@ -1290,8 +1306,8 @@ static void drop_graph(orbhip_extractor *e)
 static void free_geometry(orbhip_extractor *e)
 {
     drop_graph(e);
-    (void)hipFree(e->d_cells); (void)hipFree(e->d_cells2); (void)hipFree(e->d_tiles); (void)hipFree(e->d_tabs);
-    e->d_cells = nullptr; e->d_cells2 = nullptr; e->d_tiles = nullptr; e->d_tabs = nullptr;
+    (void)hipFree(e->d_cells); (void)hipFree(e->d_cells2); (void)hipFree(e->d_tiles);
+    e->d_cells = nullptr; e->d_cells2 = nullptr; e->d_tiles = nullptr;
     e->bound = false;
 }
 static void free_batch(orbhip_extractor *e)
@@ -1317,7 +1333,6 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
     memset(&G, 0, sizeof(G));
     G.nlevels = e->nlevels; G.rows = rows; G.cols = cols; G.ini_th = e->iniTh; G.min_th = e->minTh;
     e->cells.clear(); e->tiles.clear();
-    std::vector<short> tabs;
     unsigned off = 0;
     int kp_base = 0, cand_base = 0, slot_cap = 1;
     for (int l = 0; l < e->nlevels; ++l) {
@@ -1375,41 +1390,6 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         L.hX = (float)bw / nIni;
         L.kp_cap = std::max(L.quota + 3, 4 * nIni);
         L.kp_base = kp_base; kp_base += L.kp_cap;
-        // resize tables for level l (from level l-1), OpenCV fixed-point arithmetic
-        auto align8 = [&]() { while (tabs.size() & 7) tabs.push_back(0); };
-        align8();
-        L.xtab = L.atab = L.ytab = (int)tabs.size();
-        if (l > 0) {
-            const int sw = G.lv[l - 1].w, shh = G.lv[l - 1].h;
-            const double scale_x = 1. / ((double)L.w / sw), scale_y = 1. / ((double)L.h / shh);
-            std::vector<short> sxs, alph;
-            for (int dx = 0; dx < L.w; ++dx) {
-                float fx = (float)((dx + 0.5) * scale_x - 0.5);
-                int sx = (int)floor(fx);
-                fx -= sx;
-                if (sx < 0) { fx = 0; sx = 0; }
-                if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
-                sxs.push_back((short)sx);
-                alph.push_back((short)cv_round((1.f - fx) * 2048));
-                alph.push_back((short)cv_round(fx * 2048));
-            }
-            tabs.insert(tabs.end(), sxs.begin(), sxs.end());
-            align8();
-            L.atab = (int)tabs.size();
-            tabs.insert(tabs.end(), alph.begin(), alph.end());
-            align8();
-            L.ytab = (int)tabs.size();
-            for (int dy = 0; dy < L.h; ++dy) {
-                float fy = (float)((dy + 0.5) * scale_y - 0.5);
-                int sy = (int)floor(fy);
-                fy -= sy;
-                int sy0 = sy < 0 ? 0 : (sy < shh ? sy : shh - 1);
-                int sy1 = sy + 1 < 0 ? 0 : (sy + 1 < shh ? sy + 1 : shh - 1);
-                tabs.push_back((short)sy0); tabs.push_back((short)sy1);
-                tabs.push_back((short)cv_round((1.f - fy) * 2048));
-                tabs.push_back((short)cv_round(fy * 2048));
-            }
-        }
         // blur tiles
         for (int ty = 0; ty * kBlurTH < L.h; ++ty)
             for (int tx = 0; tx * kBlurTW < L.w; ++tx) {
@@ -1491,9 +1471,6 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
     }
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_tiles, e->tiles.size() * sizeof(TileDesc)));
     ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_tiles, e->tiles.data(), e->tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, e->stream));
-    if (tabs.empty()) tabs.push_back(0);
-    ORBHIP_HIP_CHECK(hipMalloc(&e->d_tabs, tabs.size() * sizeof(short)));
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_tabs, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice, e->stream));
     // uploads go through the handle's own stream (a legacy-stream hipMemcpy would tangle with another host thread's
     // stream capture: the stereo constructor runs two extractors on two threads); the host vectors die at return
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
@@ -1550,7 +1527,9 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         for (int l = 1; l < G.nlevels; ++l) {
             const LevelGeom &Ll = G.lv[l];
             int nl = (Ll.pitch >> 2) * ((Ll.prows + kPyrRows - 1) / kPyrRows);
-            hipLaunchKernelGGL(k_pyr_resize, dim3((nl + 255) / 256, batch), dim3(256), 0, s, b_pyr, G, l, e->d_tabs);
+            const LevelGeom &Pl = G.lv[l - 1];
+            const ResizeScale RS = {1. / ((double)Ll.w / Pl.w), 1. / ((double)Ll.h / Pl.h)};   // OpenCV: scale = 1. / ((double)dst / src)
+            hipLaunchKernelGGL(k_pyr_resize, dim3((nl + 255) / 256, batch), dim3(256), 0, s, b_pyr, G, l, RS);
         }
     }
     if (prof) (void)hipEventRecord(ev[1], s);

@@ -66,7 +66,6 @@ struct orbhip_extractor {
     orbhip::FastCell *d_cells2 = nullptr;
     orbhip::FastParams fast_params;
     orbhip::TileDesc *d_tiles = nullptr;
-    short *d_tabs = nullptr;
     orbhip::DiscTab *d_disc = nullptr;
     orbhip::DiscTab disc_host;
     int *d_disc_off = nullptr;      // [768] byte offsets of the disc pixels inside the staged 31 x 36-byte LDS tile

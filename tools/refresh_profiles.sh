@@ -1,21 +1,27 @@
 #!/bin/bash
 # Regenerates the measurement artefacts kept under profiles/ (run on the GPU box through gpurun):
-#   kernel-trace stats (default 2 pipelines), bench line under the profiler, PMC passes (1 pipeline),
-#   plain bench line, matcher latencies.  Outputs land in gpurun_out/refresh/.
+#   kernel-trace stats for the default two pipelines and for one pipeline alone, PMC passes (1 pipeline),
+#   the plain bench line, host-path rates.  Outputs land in gpurun_out/refresh/.
 set -e
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-match > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_handles2.csv
-echo "stats done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof_handles2.json 2> $OUT/stats2.err
+cp $(find $OUT/stats2 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_handles2.csv
+echo "stats (2 pipelines) done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --handles 1 --frames-per-gpu 64 > $OUT/bench_under_rocprof_handles1.json 2> $OUT/stats1.err
+cp $(find $OUT/stats1 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_handles1.csv
+echo "stats (1 pipeline) done"
 bash $R/tools/pmc_profile.sh > $OUT/pmc.log 2>&1
 cd $R
 python3 tools/pmc_summarize.py gpurun_out/pmc > $OUT/pmc_summary.json
 echo "pmc done"
 python3 bench.py > $OUT/bench_final.json 2> $OUT/bench_final.err
 echo "bench done"
+python3 tools/bench_host_path.py > $OUT/host_path.json 2> $OUT/host_path.err
+python3 tools/bench_host_path.py --pinned > $OUT/host_path_pinned.json 2>> $OUT/host_path.err
 python3 tools/bench_matchers.py > $OUT/matcher_latency.json 2> $OUT/matcher_latency.err
+rm -rf $OUT/stats2 $OUT/stats1
 cat $OUT/bench_final.json
-cat $OUT/matcher_latency.json
+cat $OUT/host_path.json $OUT/host_path_pinned.json
