@@ -410,6 +410,43 @@ int orbhip_frustum_queries(orbhip_matcher *m, const orbhip_camera *cam, const fl
                            const float *normal, const float *max_dist, const float *min_dist, const uint8_t *flags,
                            float viewing_cos_limit, float th, orbhip_query *q, float *view_cos);
 
+/* Prologue of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:853-888), Fuse(pKF, Scw, ...) (:1005-1048) and
+ * of one direction of SearchBySim3 (:1155-1180 / :1235-1260): projection of n map points into a key frame, written
+ * as orbhip_query records for orbhip_search_best_in_window (level window [pred-1, pred], radius th*scale[pred]).
+ *   mode 0 (Fuse): T1 = [Rcw | tcw] (for the Sim3 overload the caller passes Rcw = sRcw/scw, tcw = t/scw, :1000-1003);
+ *     gates: depth, KeyFrame::IsInImage, scale-invariance range on |X - Ow|, viewing angle PO.dot(Pn) >= 0.5*dist3D;
+ *     q.ur = u - bf*invz for the stereo chi-square gate of the search.
+ *   mode 1 (SearchBySim3): T1 = [R1w | t1w], T2 = [sR21 | t21] (the caller computes them as :1119-1121); gates: depth,
+ *     IsInImage, range on |Pc2|; no normal.
+ * double_invz: invz = 1.0/z evaluated in double (:1156, :1017) or 1/z in float (:862).  flags: ORBHIP_POINT_PRESENT =
+ * map point exists, !isBad(), not IsInKeyFrame / not already matched.  max_dist / min_dist = mfMaxDistance /
+ * mfMinDistance.  Host buffers, synchronous. */
+int orbhip_keyframe_queries(orbhip_matcher *m, const orbhip_camera *cam, int mode, int double_invz, const float *T1,
+                            const float *T2, int n, const float *world, const float *normal, const float *max_dist,
+                            const float *min_dist, const uint8_t *flags, float th, orbhip_query *q);
+
+/* ORBmatcher::Fuse up to the decision (src/ORBmatcher.cc:825-947 / :975-1075): prologue + best key point in the window
+ * with the chi-square gate; best_idx[n] / best_dist[n] out (-1 / 256 when nothing passes).  The replace-or-add decision
+ * (:949-971, :1077-1095: bestDist <= TH_LOW, pKF->GetMapPoint(bestIdx), Replace / AddObservation) touches the map
+ * graph, depends on the order of the points and stays in the caller.  sim3_form != 0: the Scw overload (invz in double).
+ * point_desc [n][32] = pMP->GetDescriptor(). */
+int orbhip_fuse(orbhip_matcher *m, const orbhip_frame_view *kf, const orbhip_camera *cam, const float *Tcw, int sim3_form,
+                int n, const float *world, const float *normal, const float *max_dist, const float *min_dist,
+                const uint8_t *flags, const uint8_t *point_desc, float th, const float *inv_level_sigma2, int32_t *best_idx,
+                int32_t *best_dist);
+
+/* ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1102-1326), complete: both projection directions, both searches
+ * (accept bestDist <= TH_HIGH) and the mutual-agreement pass.  kf1 / kf2: the key frames' keypoints, descriptors and
+ * grid; per key-frame slot i: world*[i], max/min_dist*[i], desc*[i] = the slot's map point (GetWorldPos,
+ * mfMax/MinDistance, GetDescriptor), flags*[i] = ORBHIP_POINT_PRESENT iff the slot has a good map point that is not in
+ * vpMatches12 already (:1132-1143).  matches12[n1] = matched kf2 slot or -1 (the caller sets vpMatches12[i1] =
+ * vpMapPoints2[matches12[i1]]); *nfound = the return value. */
+int orbhip_search_by_sim3(orbhip_matcher *m, const orbhip_frame_view *kf1, const orbhip_frame_view *kf2,
+                          const orbhip_camera *cam, const float *T1w, const float *T2w, const float *S21, const float *S12,
+                          const float *world1, const float *max_dist1, const float *min_dist1, const uint8_t *flags1,
+                          const uint8_t *desc1, const float *world2, const float *max_dist2, const float *min_dist2,
+                          const uint8_t *flags2, const uint8_t *desc2, float th, int32_t *matches12, int *nfound);
+
 /* Device-resident, batched.  Frames live in the extractor's output layout (d_kps [frames][cap] orbhip_keypoint,
  * d_desc [frames][cap][32], d_n [frames] int32); pair p has CurrentFrame = frame cur_first + p*cur_step and
  * LastFrame = frame last_first + p*last_step.  d_Tcw / d_Tlw [pairs][12] float; d_world [frames][cap][3] float and

@@ -106,6 +106,12 @@ def lib():
         L.oracle_frustum_queries.restype = None
         L.oracle_frustum_queries.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.oracle_keyframe_queries.restype = None
+        L.oracle_keyframe_queries.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.oracle_search_by_sim3.restype = C.c_int
+        L.oracle_search_by_sim3.argtypes = [C.POINTER(Frame), C.POINTER(Frame), C.POINTER(Camera)] + [C.c_void_p] * 14 + \
+            [C.c_float, C.c_void_p]
         L.oracle_search_by_projection_frame.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p,
                                                         C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_search_by_projection_block.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
@@ -310,6 +316,35 @@ def frustum_queries(cam, Tcw, world, normal, max_dist, min_dist, flags, viewing_
     lib().oracle_frustum_queries(C.byref(oc), _p(Tc), len(world), _p(world), _p(normal), _p(mx), _p(mn), _p(flags),
                                  float(viewing_cos_limit), float(th), _p(q), _p(vc))
     return q, vc
+
+
+def keyframe_queries(cam, mode, double_invz, T1, T2, world, normal, max_dist, min_dist, flags, th):
+    T1 = np.ascontiguousarray(np.asarray(T1, np.float32)[:3, :4])
+    T2 = None if T2 is None else np.ascontiguousarray(np.asarray(T2, np.float32)[:3, :4])
+    world = np.ascontiguousarray(world, np.float32).reshape(-1, 3)
+    normal = None if normal is None else np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+    mx, mn = np.ascontiguousarray(max_dist, np.float32), np.ascontiguousarray(min_dist, np.float32)
+    flags = np.ascontiguousarray(flags, np.uint8)
+    q = np.zeros(len(world), QUERY_DTYPE)
+    oc = camera_from(cam)
+    lib().oracle_keyframe_queries(C.byref(oc), int(mode), int(double_invz), _p(T1), _p(T2), len(world), _p(world), _p(normal),
+                                  _p(mx), _p(mn), _p(flags), float(th), _p(q))
+    return q
+
+
+def search_by_sim3(kf1, kf2, cam, T1w, T2w, S21, S12, pts1, pts2, th):
+    mats = [np.ascontiguousarray(np.asarray(T, np.float32)[:3, :4]) for T in (T1w, T2w, S21, S12)]
+    a = []
+    for p in (pts1, pts2):
+        a.append((np.ascontiguousarray(p[0], np.float32).reshape(-1, 3), np.ascontiguousarray(p[1], np.float32),
+                  np.ascontiguousarray(p[2], np.float32), np.ascontiguousarray(p[3], np.uint8),
+                  np.ascontiguousarray(p[4], np.uint8).reshape(-1, 32)))
+    m12 = np.full(max(kf1.n, 1), -1, np.int32)
+    oc = camera_from(cam)
+    n = lib().oracle_search_by_sim3(C.byref(kf1), C.byref(kf2), C.byref(oc), _p(mats[0]), _p(mats[1]), _p(mats[2]), _p(mats[3]),
+                                    _p(a[0][0]), _p(a[0][1]), _p(a[0][2]), _p(a[0][3]), _p(a[0][4]),
+                                    _p(a[1][0]), _p(a[1][1]), _p(a[1][2]), _p(a[1][3]), _p(a[1][4]), float(th), _p(m12))
+    return n, m12[:kf1.n].copy()
 
 
 def search_by_projection_block(cur, queries, qdesc, taken=None, max_dist=100, check_ori=True):

@@ -1780,3 +1780,87 @@ void oracle_frustum_queries(const oracle_camera *cam, const float *Tcw, int n, c
         if (view_cos) view_cos[i] = viewCos;
     }
 }
+
+static int predict_scale(float max_dist, float dist, const oracle_camera *cam)   /* MapPoint::PredictScale, MapPoint.cc:385-418 */
+{
+    const float ratio = max_dist / dist;
+    const float fl = ceilf(oracle_det_logf(ratio) / cam->log_scale_factor);
+    int nScale = fl >= (float)cam->n_levels ? cam->n_levels - 1 : (fl < 0 ? 0 : (int)fl);
+    if (!(fl == fl)) nScale = 0;
+    return nScale;
+}
+
+void oracle_keyframe_queries(const oracle_camera *cam, int mode, int double_invz, const float *T1, const float *T2, int n,
+                             const float *world, const float *normal, const float *max_dist, const float *min_dist,
+                             const uint8_t *flags, float th, oracle_query *q)
+{
+    float Ow[3] = {0, 0, 0};
+    if (mode == 0) for (int i = 0; i < 3; ++i) Ow[i] = -((T1[0 + i] * T1[3] + T1[4 + i] * T1[7]) + T1[8 + i] * T1[11]);
+    for (int i = 0; i < n; ++i) {
+        memset(&q[i], 0, sizeof(q[i]));
+        if (!(flags[i] & ORACLE_POINT_PRESENT)) continue;
+        const float *P = world + 3 * i;
+        float X = dot3_row(T1, P[0], P[1], P[2], T1[3]);
+        float Y = dot3_row(T1 + 4, P[0], P[1], P[2], T1[7]);
+        float Z = dot3_row(T1 + 8, P[0], P[1], P[2], T1[11]);
+        if (mode == 1) {
+            const float x1 = X, y1 = Y, z1 = Z;
+            X = dot3_row(T2, x1, y1, z1, T2[3]);
+            Y = dot3_row(T2 + 4, x1, y1, z1, T2[7]);
+            Z = dot3_row(T2 + 8, x1, y1, z1, T2[11]);
+        }
+        if (Z < 0.0f) continue;
+        const float invz = double_invz ? (float)(1.0 / (double)Z) : 1.0f / Z;
+        const float x = X * invz, y = Y * invz;
+        const float u = cam->fx * x + cam->cx, v = cam->fy * y + cam->cy;
+        if (!(u >= cam->min_x && u < cam->max_x && v >= cam->min_y && v < cam->max_y)) continue;   /* KeyFrame::IsInImage */
+        const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+        float dist3D;
+        if (mode == 0) {
+            const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+            dist3D = (float)sqrt(((double)PO[0] * PO[0] + (double)PO[1] * PO[1]) + (double)PO[2] * PO[2]);
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            const float *Pn = normal + 3 * i;
+            const double dot = ((double)PO[0] * Pn[0] + (double)PO[1] * Pn[1]) + (double)PO[2] * Pn[2];
+            if (dot < 0.5 * (double)dist3D) continue;
+        } else {
+            dist3D = (float)sqrt(((double)X * X + (double)Y * Y) + (double)Z * Z);
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+        }
+        const int lvl = predict_scale(max_dist[i], dist3D, cam);
+        q[i].valid = 1;
+        q[i].u = u; q[i].v = v;
+        q[i].radius = th * cam->scale_factors[lvl];
+        q[i].min_level = lvl - 1; q[i].max_level = lvl;
+        q[i].ur = mode == 0 ? u - cam->mbf * invz : 0.0f;
+        q[i].level_aux = lvl;
+    }
+}
+
+int oracle_search_by_sim3(const oracle_frame *kf1, const oracle_frame *kf2, const oracle_camera *cam, const float *T1w,
+                          const float *T2w, const float *S21, const float *S12, const float *world1, const float *max1,
+                          const float *min1, const uint8_t *flags1, const uint8_t *desc1, const float *world2,
+                          const float *max2, const float *min2, const uint8_t *flags2, const uint8_t *desc2, float th,
+                          int32_t *matches12)
+{
+    const int n1 = kf1->n, n2 = kf2->n;
+    oracle_query *q1 = (oracle_query *)malloc(sizeof(oracle_query) * (size_t)(n1 + 1));
+    oracle_query *q2 = (oracle_query *)malloc(sizeof(oracle_query) * (size_t)(n2 + 1));
+    int32_t *m1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n1 + 1)), *d1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n1 + 1));
+    int32_t *m2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 + 1)), *d2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 + 1));
+    oracle_keyframe_queries(cam, 1, 1, T1w, S21, n1, world1, NULL, max1, min1, flags1, th, q1);   /* KF1 points into KF2 */
+    oracle_keyframe_queries(cam, 1, 1, T2w, S12, n2, world2, NULL, max2, min2, flags2, th, q2);   /* KF2 points into KF1 */
+    oracle_search_best_in_window(kf2, q1, desc1, n1, NULL, m1, d1);
+    oracle_search_best_in_window(kf1, q2, desc2, n2, NULL, m2, d2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; ++i1) {
+        matches12[i1] = -1;
+        const int idx2 = (m1[i1] >= 0 && d1[i1] <= TH_HIGH) ? m1[i1] : -1;      /* vnMatch1, :1222-1225 */
+        if (idx2 >= 0) {
+            const int idx1 = (m2[idx2] >= 0 && d2[idx2] <= TH_HIGH) ? m2[idx2] : -1;
+            if (idx1 == i1) { matches12[i1] = idx2; nFound++; }
+        }
+    }
+    free(q1); free(q2); free(m1); free(d1); free(m2); free(d2);
+    return nFound;
+}

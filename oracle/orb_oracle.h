@@ -234,6 +234,26 @@ void oracle_frustum_queries(const oracle_camera *cam, const float *Tcw, int n, c
                             const float *max_dist, const float *min_dist, const uint8_t *flags, float viewing_cos_limit,
                             float th, oracle_query *q, float *view_cos);
 
+/* Prologue of ORBmatcher::Fuse (src/ORBmatcher.cc:853-888, Sim3 overload :1005-1048) and of one direction of
+ * SearchBySim3 (:1155-1180, :1235-1260): projection of n map points into a key frame.
+ * mode 0 (Fuse): Pc = Rcw*X + tcw; viewing-angle gate PO.dot(Pn) >= 0.5*dist3D; ur = u - bf*invz; dist3D = |X - Ow|.
+ * mode 1 (SearchBySim3): Pc = T2*(T1*X) with T1 = [R1w|t1w], T2 = [sR21|t21]; dist3D = |Pc|; no normal gate.
+ * double_invz: invz = 1.0/z (double, rounded to float; Fuse-Sim3 and SearchBySim3) or 1/z in float (Fuse).
+ * IsInImage is KeyFrame::IsInImage (strict < on the max bounds, src/KeyFrame.cc:610-613).  Level window [pred-1, pred]. */
+void oracle_keyframe_queries(const oracle_camera *cam, int mode, int double_invz, const float *T1, const float *T2, int n,
+                             const float *world, const float *normal, const float *max_dist, const float *min_dist,
+                             const uint8_t *flags, float th, oracle_query *q);
+
+/* ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1102-1326) on flat arrays: both directions + the agreement pass.
+ * T1w / T2w = key-frame poses, S21 = [sR21 | t21], S12 = [sR12 | t12] (3x4, computed by the caller as :1119-1121).
+ * flags1 / flags2: ORACLE_POINT_PRESENT = map point exists, not bad, not already matched.  desc1 / desc2 =
+ * pMP->GetDescriptor() per key-frame slot.  matches12[n1] = kf2 slot or -1; returns nFound. */
+int oracle_search_by_sim3(const oracle_frame *kf1, const oracle_frame *kf2, const oracle_camera *cam, const float *T1w,
+                          const float *T2w, const float *S21, const float *S12, const float *world1, const float *max1,
+                          const float *min1, const uint8_t *flags1, const uint8_t *desc1, const float *world2,
+                          const float *max2, const float *min2, const uint8_t *flags2, const uint8_t *desc2, float th,
+                          int32_t *matches12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,11 @@ SYMBOLS = [
                                                      _f, _i, _vp, _vp]),
     ("orbhip_project_last_frame", _i, [_vp, C.POINTER(Camera), _vp, _vp, _i, _vp, _vp, _vp, _f, _i, _vp]),
     ("orbhip_frustum_queries", _i, [_vp, C.POINTER(Camera), _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
+    ("orbhip_keyframe_queries", _i, [_vp, C.POINTER(Camera), _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    ("orbhip_fuse", _i, [_vp, C.POINTER(FrameView), C.POINTER(Camera), _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp,
+                         _vp]),
+    ("orbhip_search_by_sim3", _i, [_vp, C.POINTER(FrameView), C.POINTER(FrameView), C.POINTER(Camera), _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _pi]),
     ("orbhip_project_last_frame_device", _i, [_vp, _i, C.POINTER(Camera), _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _i,
                                               _vp, _vp]),
     ("orbhip_track_last_frame_device", _i, [_vp, _i, C.POINTER(Camera), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp,

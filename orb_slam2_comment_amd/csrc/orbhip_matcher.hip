@@ -1485,6 +1485,73 @@ __global__ __launch_bounds__(256) void k_init_update_prev(const orbhip_keypoint 
     pm[0] = kp.x; pm[1] = kp.y;
 }
 
+// Prologue of ORBmatcher::Fuse (both overloads) and of one direction of SearchBySim3: see include/orbhip.h
+// (orbhip_keyframe_queries).  One thread per map point.
+struct KfQueryArgs {
+    const float *T1, *T2;                   // 12 floats each (T2 unused in mode 0)
+    const float *world, *normal, *max_dist, *min_dist;
+    const uint8_t *flags;
+    orbhip_query *q;
+    int n, mode, double_invz;
+};
+__global__ __launch_bounds__(256) void k_keyframe_queries(KfQueryArgs A, orbhip_camera cam, float th)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    orbhip_query Q;
+    Q.valid = 0; Q.u = 0; Q.v = 0; Q.radius = 0; Q.min_level = 0; Q.max_level = 0; Q.ur = 0; Q.level_aux = 0; Q.angle = 0; Q.observed = 0;
+    do {
+        if (!(A.flags[i] & ORBHIP_POINT_PRESENT)) break;
+        const float *T1 = A.T1;
+        const float *P = A.world + (size_t)i * 3;
+        const float px = P[0], py = P[1], pz = P[2];
+        float X = dot3_row(T1, px, py, pz, T1[3]);
+        float Y = dot3_row(T1 + 4, px, py, pz, T1[7]);
+        float Z = dot3_row(T1 + 8, px, py, pz, T1[11]);
+        if (A.mode == 1) {
+            const float *T2 = A.T2;
+            const float x1 = X, y1 = Y, z1 = Z;
+            X = dot3_row(T2, x1, y1, z1, T2[3]);
+            Y = dot3_row(T2 + 4, x1, y1, z1, T2[7]);
+            Z = dot3_row(T2 + 8, x1, y1, z1, T2[11]);
+        }
+        if (Z < 0.0f) break;
+        const float invz = A.double_invz ? (float)__ddiv_rn(1.0, (double)Z) : __fdiv_rn(1.0f, Z);
+        const float x = __fmul_rn(X, invz), y = __fmul_rn(Y, invz);
+        const float u = __fadd_rn(__fmul_rn(cam.fx, x), cam.cx), v = __fadd_rn(__fmul_rn(cam.fy, y), cam.cy);
+        if (!(u >= cam.min_x && u < cam.max_x && v >= cam.min_y && v < cam.max_y)) break;   // KeyFrame::IsInImage
+        const float md = A.max_dist[i];
+        const float maxDistance = __fmul_rn(1.2f, md), minDistance = __fmul_rn(0.8f, A.min_dist[i]);
+        float dist3D;
+        if (A.mode == 0) {
+            float Ow[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                Ow[c] = -__fadd_rn(__fadd_rn(__fmul_rn(T1[c], T1[3]), __fmul_rn(T1[4 + c], T1[7])), __fmul_rn(T1[8 + c], T1[11]));
+            const float ox = __fsub_rn(px, Ow[0]), oy = __fsub_rn(py, Ow[1]), oz = __fsub_rn(pz, Ow[2]);
+            const double ss = __dadd_rn(__dadd_rn(__dmul_rn((double)ox, (double)ox), __dmul_rn((double)oy, (double)oy)), __dmul_rn((double)oz, (double)oz));
+            dist3D = (float)__dsqrt_rn(ss);
+            if (dist3D < minDistance || dist3D > maxDistance) break;
+            const float *Pn = A.normal + (size_t)i * 3;
+            const double dot = __dadd_rn(__dadd_rn(__dmul_rn((double)ox, (double)Pn[0]), __dmul_rn((double)oy, (double)Pn[1])), __dmul_rn((double)oz, (double)Pn[2]));
+            if (dot < __dmul_rn(0.5, (double)dist3D)) break;
+        } else {
+            const double ss = __dadd_rn(__dadd_rn(__dmul_rn((double)X, (double)X), __dmul_rn((double)Y, (double)Y)), __dmul_rn((double)Z, (double)Z));
+            dist3D = (float)__dsqrt_rn(ss);
+            if (dist3D < minDistance || dist3D > maxDistance) break;
+        }
+        const float fl = ceilf(__fdiv_rn(det_logf(__fdiv_rn(md, dist3D)), cam.log_scale_factor));
+        int lvl = fl >= (float)cam.n_levels ? cam.n_levels - 1 : (fl < 0 ? 0 : (int)fl);
+        if (!(fl == fl)) lvl = 0;
+        Q.valid = 1; Q.u = u; Q.v = v;
+        Q.radius = __fmul_rn(th, cam.scale_factors[min(max(lvl, 0), ORBHIP_MAX_LEVELS - 1)]);
+        Q.min_level = lvl - 1; Q.max_level = lvl;
+        Q.ur = A.mode == 0 ? __fsub_rn(u, __fmul_rn(cam.mbf, invz)) : 0.0f;
+        Q.level_aux = lvl;
+    } while (0);
+    A.q[i] = Q;
+}
+
 struct StereoGeom {
     int nlevels, nrows;
     const uint8_t *left[ORBHIP_MAX_LEVELS], *right[ORBHIP_MAX_LEVELS];
@@ -2777,6 +2844,84 @@ int orbhip_dev_resolve_stats(unsigned int out[4])
     unsigned int z[4] = {0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(orbhip::g_resolve_stats), sizeof(z)) != hipSuccess) return ORBHIP_E_HIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(orbhip::g_resolve_stats), z, sizeof(z)) != hipSuccess) return ORBHIP_E_HIP;
+    return ORBHIP_OK;
+}
+
+int orbhip_keyframe_queries(orbhip_matcher *m, const orbhip_camera *cam, int mode, int double_invz, const float *T1,
+                            const float *T2, int n, const float *world, const float *normal, const float *max_dist,
+                            const float *min_dist, const uint8_t *flags, float th, orbhip_query *q)
+{
+    if (!m || !cam || n < 0 || !T1 || !q || (mode != 0 && mode != 1) || (mode == 1 && !T2) || cam->n_levels < 1 ||
+        cam->n_levels > ORBHIP_MAX_LEVELS)
+        return ORBHIP_E_ARG;
+    if (n == 0) return ORBHIP_OK;
+    if (!world || !max_dist || !min_dist || !flags || (mode == 0 && !normal)) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    Stage st;
+    int rc = stage_begin(m, 2 * al256(48) + 2 * al256((size_t)n * 12) + 2 * al256((size_t)n * 4) + al256((size_t)n), &st);
+    if (rc) return rc;
+    KfQueryArgs A;
+    A.T1 = (const float *)st.put(T1, 48);
+    A.T2 = T2 ? (const float *)st.put(T2, 48) : nullptr;
+    A.world = (const float *)st.put(world, (size_t)n * 12);
+    A.normal = normal ? (const float *)st.put(normal, (size_t)n * 12) : nullptr;
+    A.max_dist = (const float *)st.put(max_dist, (size_t)n * 4);
+    A.min_dist = (const float *)st.put(min_dist, (size_t)n * 4);
+    A.flags = (const uint8_t *)st.put(flags, (size_t)n);
+    A.n = n; A.mode = mode; A.double_invz = double_invz;
+    if ((rc = stage_commit(m, &st))) return rc;
+    void *p;
+    if ((rc = scratch(m, S_Q, (size_t)n * sizeof(orbhip_query), &p))) return rc;
+    A.q = (orbhip_query *)p;
+    hipLaunchKernelGGL(k_keyframe_queries, dim3((n + 255) / 256), dim3(256), 0, m->stream, A, *cam, th);
+    ORBHIP_HIP_CHECK(hipGetLastError());
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(q, p, (size_t)n * sizeof(orbhip_query), hipMemcpyDeviceToHost, m->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBHIP_OK;
+}
+
+int orbhip_fuse(orbhip_matcher *m, const orbhip_frame_view *kf, const orbhip_camera *cam, const float *Tcw, int sim3_form,
+                int n, const float *world, const float *normal, const float *max_dist, const float *min_dist,
+                const uint8_t *flags, const uint8_t *point_desc, float th, const float *inv_level_sigma2, int32_t *best_idx,
+                int32_t *best_dist)
+{
+    if (!m || !kf || n < 0 || (n > 0 && (!best_idx || !best_dist || !point_desc))) return ORBHIP_E_ARG;
+    if (n == 0) return ORBHIP_OK;
+    static thread_local std::vector<orbhip_query> q;
+    q.resize((size_t)n);
+    int rc = orbhip_keyframe_queries(m, cam, 0, sim3_form ? 1 : 0, Tcw, nullptr, n, world, normal, max_dist, min_dist, flags, th, q.data());
+    if (rc) return rc;
+    return orbhip_search_best_in_window(m, kf, q.data(), point_desc, n, 1, inv_level_sigma2, best_idx, best_dist);
+}
+
+int orbhip_search_by_sim3(orbhip_matcher *m, const orbhip_frame_view *kf1, const orbhip_frame_view *kf2,
+                          const orbhip_camera *cam, const float *T1w, const float *T2w, const float *S21, const float *S12,
+                          const float *world1, const float *max_dist1, const float *min_dist1, const uint8_t *flags1,
+                          const uint8_t *desc1, const float *world2, const float *max_dist2, const float *min_dist2,
+                          const uint8_t *flags2, const uint8_t *desc2, float th, int32_t *matches12, int *nfound)
+{
+    if (!m || !kf1 || !kf2 || !cam || !T1w || !T2w || !S21 || !S12 || !matches12 || !nfound) return ORBHIP_E_ARG;
+    const int n1 = kf1->n, n2 = kf2->n;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    *nfound = 0;
+    if (n1 == 0 || n2 == 0) return ORBHIP_OK;
+    static thread_local std::vector<orbhip_query> q1, q2;
+    static thread_local std::vector<int32_t> m1, d1, m2, d2;
+    q1.resize(n1); q2.resize(n2); m1.resize(n1); d1.resize(n1); m2.resize(n2); d2.resize(n2);
+    int rc;
+    // KF1's map points into KF2 (:1146-1226) and KF2's into KF1 (:1228-1303)
+    if ((rc = orbhip_keyframe_queries(m, cam, 1, 1, T1w, S21, n1, world1, nullptr, max_dist1, min_dist1, flags1, th, q1.data()))) return rc;
+    if ((rc = orbhip_keyframe_queries(m, cam, 1, 1, T2w, S12, n2, world2, nullptr, max_dist2, min_dist2, flags2, th, q2.data()))) return rc;
+    if ((rc = orbhip_search_best_in_window(m, kf2, q1.data(), desc1, n1, 0, nullptr, m1.data(), d1.data()))) return rc;
+    if ((rc = orbhip_search_best_in_window(m, kf1, q2.data(), desc2, n2, 0, nullptr, m2.data(), d2.data()))) return rc;
+    int found = 0;
+    for (int i1 = 0; i1 < n1; ++i1) {   // agreement, :1306-1323
+        const int idx2 = (m1[i1] >= 0 && d1[i1] <= TH_HIGH) ? m1[i1] : -1;
+        if (idx2 < 0) continue;
+        const int idx1 = (m2[idx2] >= 0 && d2[idx2] <= TH_HIGH) ? m2[idx2] : -1;
+        if (idx1 == i1) { matches12[i1] = idx2; ++found; }
+    }
+    *nfound = found;
     return ORBHIP_OK;
 }
 

@@ -309,6 +309,50 @@ class ORBmatcher:
               "orbhip_frustum_queries")
         return q, vc
 
+    # -- Fuse x2 (src/ORBmatcher.cc:825-1100) and SearchBySim3 (:1102-1326), prologue included ---------------------
+    @staticmethod
+    def _pts(world, normal, max_dist, min_dist, flags):
+        w = np.ascontiguousarray(world, np.float32).reshape(-1, 3)
+        nn = None if normal is None else np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        return (w, nn, np.ascontiguousarray(max_dist, np.float32), np.ascontiguousarray(min_dist, np.float32),
+                np.ascontiguousarray(flags, np.uint8))
+
+    def KeyFrameQueries(self, cam, mode, double_invz, T1, T2, world, normal, max_dist, min_dist, flags, th):
+        T1 = np.ascontiguousarray(np.asarray(T1, np.float32)[:3, :4])
+        T2 = None if T2 is None else np.ascontiguousarray(np.asarray(T2, np.float32)[:3, :4])
+        w, nn, mx, mn, fg = self._pts(world, normal, max_dist, min_dist, flags)
+        q = np.zeros(len(w), QUERY_DTYPE)
+        check(self._lib.orbhip_keyframe_queries(self._h, C.byref(cam), int(mode), int(double_invz), ptr(T1), ptr(T2), len(w),
+                                                ptr(w), ptr(nn), ptr(mx), ptr(mn), ptr(fg), float(th), ptr(q)),
+              "orbhip_keyframe_queries")
+        return q
+
+    def Fuse(self, KF, cam, Tcw, world, normal, max_dist, min_dist, flags, point_desc, th, inv_level_sigma2, sim3_form=False):
+        """Fuse up to the decision: (best_idx[n], best_dist[n]); the caller applies bestDist <= TH_LOW and the
+        replace-or-add side effects in order."""
+        Tc = np.ascontiguousarray(np.asarray(Tcw, np.float32)[:3, :4])
+        w, nn, mx, mn, fg = self._pts(world, normal, max_dist, min_dist, flags)
+        pd = np.ascontiguousarray(point_desc, np.uint8).reshape(-1, 32)
+        sig = np.ascontiguousarray(inv_level_sigma2, np.float32)
+        bi, bd = np.full(max(len(w), 1), -1, np.int32), np.full(max(len(w), 1), 256, np.int32)
+        v = KF.c_view()
+        check(self._lib.orbhip_fuse(self._h, C.byref(v), C.byref(cam), ptr(Tc), int(sim3_form), len(w), ptr(w), ptr(nn), ptr(mx),
+                                    ptr(mn), ptr(fg), ptr(pd), float(th), ptr(sig), ptr(bi), ptr(bd)), "orbhip_fuse")
+        return bi[:len(w)].copy(), bd[:len(w)].copy()
+
+    def SearchBySim3(self, KF1, KF2, cam, T1w, T2w, S21, S12, pts1, pts2, th):
+        """pts = (world, max_dist, min_dist, flags, desc) per key-frame slot.  Returns (nFound, matches12[N1])."""
+        mats = [np.ascontiguousarray(np.asarray(T, np.float32)[:3, :4]) for T in (T1w, T2w, S21, S12)]
+        a = [self._pts(p[0], None, p[1], p[2], p[3]) + (np.ascontiguousarray(p[4], np.uint8).reshape(-1, 32),) for p in (pts1, pts2)]
+        m12 = np.full(max(KF1.N, 1), -1, np.int32)
+        n = C.c_int()
+        v1, v2 = KF1.c_view(), KF2.c_view()
+        check(self._lib.orbhip_search_by_sim3(self._h, C.byref(v1), C.byref(v2), C.byref(cam), ptr(mats[0]), ptr(mats[1]),
+                                              ptr(mats[2]), ptr(mats[3]), ptr(a[0][0]), ptr(a[0][2]), ptr(a[0][3]), ptr(a[0][4]),
+                                              ptr(a[0][5]), ptr(a[1][0]), ptr(a[1][2]), ptr(a[1][3]), ptr(a[1][4]), ptr(a[1][5]),
+                                              float(th), ptr(m12), C.byref(n)), "orbhip_search_by_sim3")
+        return n.value, m12[:KF1.N].copy()
+
     def ProjectLastFrameDevice(self, pairs, cam, d_Tcw, d_Tlw, d_kps, d_n, cap, last_first, last_step, d_world, d_flags, th,
                                bMono, d_q, d_nq):
         check(self._lib.orbhip_project_last_frame_device(self._h, pairs, C.byref(cam), d_Tcw, d_Tlw, d_kps, d_n, cap,

@@ -277,3 +277,90 @@ def test_search_for_initialization_device_matches_oracle(env):
                 assert nm[p] == on and np.array_equal(m12[p, :n[f1]], om12), (p, rnd, ori)
                 assert np.array_equal(prev[p, :n[f1]], opm[p])
                 assert on > 80
+
+
+def _synthetic_map_for(kps, cam, T, rng, depth=(4, 40)):
+    """World points that project onto the given keypoints of a key frame with pose T (plus normals and ranges)."""
+    z = rng.uniform(depth[0], depth[1], len(kps)).astype(np.float32)
+    X = _back_project(kps, z, cam, T)
+    R, t = T[:3, :3].astype(np.float64), T[:3, 3].astype(np.float64)
+    Ow = -(R.T @ t)
+    view = X.astype(np.float64) - Ow
+    d = np.linalg.norm(view, axis=1)
+    nrm = view / d[:, None] + rng.normal(0, 0.25, (len(kps), 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    sf = np.float32(1.2) ** kps["octave"].astype(np.float32)
+    max_d = (d * sf * rng.uniform(0.9, 1.1, len(kps))).astype(np.float32)     # PredictScale lands near the keypoint's octave
+    min_d = (max_d / np.float32(1.2 ** 7)).astype(np.float32)
+    return X, nrm, max_d, min_d
+
+
+@pytest.mark.parametrize("sim3_form,th", [(False, 3.0), (True, 4.0)])
+def test_fuse_prologue_and_search(env, sim3_form, th):
+    """ORBmatcher::Fuse up to the decision (src/LocalMapping.cc:SearchInNeighbors th=3; LoopClosing th=4 with Scw)."""
+    pkg, M, O = env
+    rng = np.random.default_rng(11 + sim3_form)
+    ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    img = synth_frame(6)
+    k, d = ext(img)
+    sf = ext.GetScaleFactors()
+    cam = M.make_camera(KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, frame_bounds(img), sf, mbf=KITTI_BF, mb=KITTI_BF / KITTI_FX)
+    T = _pose(rng)
+    X, nrm, max_d, min_d = _synthetic_map_for(k, cam, T, rng)
+    X += rng.normal(0, 0.01, X.shape).astype(np.float32)
+    flags = (rng.random(len(k)) < 0.9).astype(np.uint8)
+    pdesc = d ^ (rng.random(d.shape) < 0.03).astype(np.uint8) * rng.integers(1, 256, d.shape, dtype=np.uint8)
+    ur = np.where(rng.random(len(k)) < 0.5, k["x"] - rng.uniform(2, 60, len(k)), -1).astype(np.float32)
+    gv, keep = pkg.FrameView(k, d, sf, frame_bounds(img), ur), []
+    ov = O.make_frame(k, d, ur, frame_bounds(img), sf, keep)
+    inv_sigma2 = (1.0 / (sf * sf)).astype(np.float32)
+    m = pkg.ORBmatcher(0.6, True)
+    q = m.KeyFrameQueries(cam, 0, sim3_form, T, None, X, nrm, max_d, min_d, flags, th)
+    oq = O.keyframe_queries(cam, 0, sim3_form, T, None, X, nrm, max_d, min_d, flags, th)
+    _assert_queries_equal(q, oq)
+    assert 200 < q["valid"].sum() < len(q)
+    bi, bd = m.Fuse(gv, cam, T, X, nrm, max_d, min_d, flags, pdesc, th, inv_sigma2, sim3_form)
+    obi, obd = O.search_best_in_window(ov, oq, pdesc, inv_sigma2)
+    assert np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    assert (bd <= 50).sum() > 150
+
+
+def test_search_by_sim3_complete(env):
+    """SearchBySim3 (src/LoopClosing.cc:ComputeSim3, th = 7.5): both directions and the agreement pass."""
+    pkg, M, O = env
+    rng = np.random.default_rng(21)
+    ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    img1, img2 = synth_frame(8), synth_frame(8, shift_xy=(4, 2))
+    k1, d1 = ext(img1)
+    k2, d2 = ext(img2)
+    sf = ext.GetScaleFactors()
+    cam = M.make_camera(KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, frame_bounds(img1), sf, mbf=KITTI_BF, mb=KITTI_BF / KITTI_FX)
+    # both key frames sit at the same place up to a small translation that reproduces the image shift at depth 12 m;
+    # the Sim3 between them is that rigid motion with scale 1.05
+    T1w = np.eye(4, dtype=np.float32)
+    T2w = np.eye(4, dtype=np.float32)
+    T2w[0, 3] = np.float32(4.0 * 12.0 / KITTI_FX); T2w[1, 3] = np.float32(2.0 * 12.0 / KITTI_FY)
+    s12 = np.float32(1.0)
+    R12, t12 = np.eye(3, dtype=np.float32), -T2w[:3, 3]              # camera 1 from camera 2
+    S12 = np.eye(4, dtype=np.float32); S12[:3, :3] = s12 * R12; S12[:3, 3] = t12
+    sR21 = (np.float32(1.0 / s12) * R12.T).astype(np.float32)
+    S21 = np.eye(4, dtype=np.float32); S21[:3, :3] = sR21; S21[:3, 3] = -(sR21 @ t12)
+    z = np.float32(12.0)
+    X1 = _back_project(k1, np.full(len(k1), z, np.float32), cam, T1w)
+    X2 = _back_project(k2, np.full(len(k2), z, np.float32), cam, T2w)
+    mx1 = (z * np.float32(1.2) ** k1["octave"].astype(np.float32)).astype(np.float32)
+    mx2 = (z * np.float32(1.2) ** k2["octave"].astype(np.float32)).astype(np.float32)
+    mn1, mn2 = (mx1 / np.float32(3.58)).astype(np.float32), (mx2 / np.float32(3.58)).astype(np.float32)
+    f1 = (rng.random(len(k1)) < 0.9).astype(np.uint8)
+    f2 = (rng.random(len(k2)) < 0.9).astype(np.uint8)
+    g1, g2 = pkg.FrameView(k1, d1, sf, frame_bounds(img1)), pkg.FrameView(k2, d2, sf, frame_bounds(img1))
+    keep = []
+    o1 = O.make_frame(k1, d1, None, frame_bounds(img1), sf, keep)
+    o2 = O.make_frame(k2, d2, None, frame_bounds(img1), sf, keep)
+    m = pkg.ORBmatcher(0.75, True)
+    n, m12 = m.SearchBySim3(g1, g2, cam, T1w, T2w, S21, S12, (X1, mx1, mn1, f1, d1), (X2, mx2, mn2, f2, d2), 7.5)
+    on, om12 = O.search_by_sim3(o1, o2, cam, T1w, T2w, S21, S12, (X1, mx1, mn1, f1, d1), (X2, mx2, mn2, f2, d2), 7.5)
+    assert n == on and np.array_equal(m12, om12)
+    assert n > 300
+    ok = m12 >= 0
+    assert (np.abs(k2["x"][m12[ok]] - k1["x"][ok] - 4) < 12).mean() > 0.95      # the matches follow the image shift
