@@ -326,6 +326,145 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, P
     }
 }
 
+// ---------------------------------------------------------------------------
+// Table-driven pyramid kernels (the default path; k_pyr_level0 / k_pyr_resize above remain for levels whose scale
+// factor puts a tap group outside an 8-byte window).  A WAVEFRONT owns kPyrRows consecutive padded destination
+// rows and a run of <= 64 lanes of one row: everything that depends on the rows (source rows, row coefficients,
+// row addresses) is wave-uniform and lives on the scalar unit; everything that depends on the column comes from a
+// per-lane table record that is the same for every row and every frame.  The REFLECT_101 frame is part of the
+// tables (a border lane gathers the reflected interior columns through the same instructions), so no wavefront
+// ever runs a second code path.
+//  * level 0 (copyMakeBorder of the input image): per lane one unaligned 16-byte load + six v_perm_b32 + one
+//    16-byte store per row;
+//  * level l >= 1 (resize INTER_LINEAR 8U + copyMakeBorder): per lane two unaligned 8-byte loads per row, and per
+//    pixel and source row v_perm_b32 (tap pair) + v_dot2_u32_u16 (Q11 horizontal filter) + v_and (the >> 4 of
+//    OpenCV's vertical pass, kept in place) + v_mul_hi_u32_u24 with the row coefficient << 12 (= (b * (h >> 4)) >> 16);
+//    a source row shared by two consecutive destination rows is filtered once (the choice is wave-uniform).
+// k_pyr_base runs level 0 and level 1 in ONE launch: level 1 reads the input image itself, not the padded level-0
+// plane, so the two do not depend on each other.
+// ---------------------------------------------------------------------------
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t mulhi24_s(uint32_t a, uint32_t sb)
+{
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %2, %1" : "=v"(r) : "v"(a), "s"(sb));
+    return r;
+}
+__device__ __forceinline__ PyrRow load_row_rec(const PyrRow *rows, int py)
+{
+    const u32x4_t raw = *reinterpret_cast<const __attribute__((address_space(4))) u32x4_t *>(reinterpret_cast<uintptr_t>(rows + py));
+    return __builtin_bit_cast(PyrRow, raw);
+}
+
+// unit -> (row group, lane's column); false when the lane has nothing to do
+__device__ __forceinline__ bool pyr_unit(const PyrLevelTab &T, int unit, int &rg, int &col)
+{
+    rg = T.nchunks == 1 ? unit : (int)__umulhi((uint32_t)unit, T.rcp_chunks);
+    const int c = unit - rg * T.nchunks;
+    const int lane = threadIdx.x & 63;
+    col = c * T.chunk_w + lane;
+    return lane < T.chunk_w && col < T.words;
+}
+
+__device__ __forceinline__ void pyr_copy_rows(const PyrLevelTab &T, int unit, const uint8_t *__restrict__ src, int stride,
+                                              uint8_t *__restrict__ dplane)
+{
+    int rg, g;
+    if (!pyr_unit(T, unit, rg, g)) return;
+    const PyrCopyCol C = reinterpret_cast<const PyrCopyCol *>(T.col)[g];
+    const uint32_t base = T.lo[g];
+    uint4 win[kPyrRows];
+#pragma unroll
+    for (int r = 0; r < kPyrRows; ++r) {
+        const int py = min(rg * kPyrRows + r, T.prows - 1);
+        const int sy = reflect101(py - kEdge, T.src_h);
+        __builtin_memcpy(&win[r], src + (size_t)((uint32_t)sy * (uint32_t)stride) + base, 16);
+    }
+#pragma unroll
+    for (int r = 0; r < kPyrRows; ++r) {
+        const int py = rg * kPyrRows + r;
+        if (py >= T.prows) break;
+        uint4 o;
+        o.x = __builtin_amdgcn_perm(win[r].y, win[r].x, C.selA[0]) | __builtin_amdgcn_perm(win[r].w, win[r].z, C.selB[0]);
+        o.y = __builtin_amdgcn_perm(win[r].y, win[r].x, C.selA[1]) | __builtin_amdgcn_perm(win[r].w, win[r].z, C.selB[1]);
+        o.z = __builtin_amdgcn_perm(win[r].y, win[r].x, C.selA[2]) | __builtin_amdgcn_perm(win[r].w, win[r].z, C.selB[2]);
+        o.w = __builtin_amdgcn_perm(win[r].y, win[r].x, C.selA[3]) | __builtin_amdgcn_perm(win[r].w, win[r].z, C.selB[3]);
+        *reinterpret_cast<uint4 *>(dplane + (size_t)((uint32_t)py * (uint32_t)T.pitch) + (uint32_t)g * 16u) = o;
+    }
+}
+
+__device__ __forceinline__ void pyr_hfilter(unsigned long long w, const PyrCol &C, uint32_t (&h)[4])
+{
+    const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = udot2(__builtin_amdgcn_perm(wh, wl, C.sel[k]), C.alv[k], 0) & ~15u;
+}
+
+__device__ __forceinline__ void pyr_resize_rows(const PyrLevelTab &T, int unit, const uint8_t *__restrict__ sroi, int spitch,
+                                                uint8_t *__restrict__ dplane)
+{
+    int rg, pw;
+    if (!pyr_unit(T, unit, rg, pw)) return;
+    const PyrCol C = reinterpret_cast<const PyrCol *>(T.col)[pw];
+    const uint32_t lo = T.lo[pw];
+    PyrRow R[kPyrRows];
+    unsigned long long w0[kPyrRows], w1[kPyrRows];
+#pragma unroll
+    for (int r = 0; r < kPyrRows; ++r) {
+        R[r] = load_row_rec(T.row, min(rg * kPyrRows + r, T.prows - 1));
+        __builtin_memcpy(&w0[r], sroi + (size_t)((uint32_t)R[r].s0 * (uint32_t)spitch) + lo, 8);
+        __builtin_memcpy(&w1[r], sroi + (size_t)((uint32_t)R[r].s1 * (uint32_t)spitch) + lo, 8);
+    }
+    uint32_t ha[4], hb[4];
+#pragma unroll
+    for (int r = 0; r < kPyrRows; ++r) {
+        if (r > 0 && R[r].s0 == R[r - 1].s1) {   // wave-uniform: the upper source row is the previous row's lower one
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ha[k] = hb[k];
+        } else {
+            pyr_hfilter(w0[r], C, ha);
+        }
+        pyr_hfilter(w1[r], C, hb);
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t v = (mulhi24_s(ha[k], R[r].B0) + mulhi24_s(hb[k], R[r].B1) + 2u) >> 2;
+            acc |= v << (8 * k);
+        }
+        const int py = rg * kPyrRows + r;
+        if (py < T.prows) *reinterpret_cast<uint32_t *>(dplane + (size_t)((uint32_t)py * (uint32_t)T.pitch) + (uint32_t)pw * 4u) = acc;
+    }
+}
+
+// level 0 + level 1 of a frame in one launch: workgroups [0, nb0) copy, the rest resize from the input image
+__global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ images, int stride, size_t frame_stride,
+                                                  uint8_t *__restrict__ pyr, uint32_t frame_bytes, PyrLevelTab T0,
+                                                  PyrLevelTab T1, int nb0)
+{
+    int bx, fr;
+    xcd_remap(bx, fr);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint8_t *src = images + (size_t)fr * frame_stride;
+    uint8_t *frame = pyr + (size_t)fr * frame_bytes;
+    if (bx < nb0) {
+        const int unit = bx * 4 + wave;
+        if (unit < T0.units) pyr_copy_rows(T0, unit, src, stride, frame + T0.plane_off);
+    } else {
+        const int unit = (bx - nb0) * 4 + wave;
+        if (unit < T1.units) pyr_resize_rows(T1, unit, src, stride, frame + T1.plane_off);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pyr_rows(uint8_t *__restrict__ pyr, uint32_t frame_bytes, PyrLevelTab T)
+{
+    int bx, fr;
+    xcd_remap(bx, fr);
+    const int unit = bx * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (unit >= T.units) return;
+    uint8_t *frame = pyr + (size_t)fr * frame_bytes;
+    pyr_resize_rows(T, unit, frame + T.src_off, T.src_pitch, frame + T.plane_off);
+}
+
 constexpr int kSubMax = 72;              // max (wCell+6), (hCell+6)
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
@@ -1306,8 +1445,8 @@ static void drop_graph(orbhip_extractor *e)
 static void free_geometry(orbhip_extractor *e)
 {
     drop_graph(e);
-    (void)hipFree(e->d_cells); (void)hipFree(e->d_cells2); (void)hipFree(e->d_tiles);
-    e->d_cells = nullptr; e->d_cells2 = nullptr; e->d_tiles = nullptr;
+    (void)hipFree(e->d_cells); (void)hipFree(e->d_cells2); (void)hipFree(e->d_tiles); (void)hipFree(e->d_pyrtab);
+    e->d_cells = nullptr; e->d_cells2 = nullptr; e->d_tiles = nullptr; e->d_pyrtab = nullptr;
     e->bound = false;
 }
 static void free_batch(orbhip_extractor *e)
@@ -1318,6 +1457,150 @@ static void free_batch(orbhip_extractor *e)
     e->d_pyr = e->d_blur = nullptr; e->d_cell_cnt = nullptr; e->d_cell_kp = nullptr; e->d_keys = nullptr;
     e->d_knode = nullptr; e->d_sel = nullptr; e->d_sel_cnt = nullptr; e->d_status = nullptr;
     e->batch_cap = 0;
+}
+
+// OpenCV's fixed-point bilinear coefficients of one destination coordinate (the host twin of resize_coef):
+// columns drop the fraction at the ends (clamp_both = false), rows clamp both taps and keep it.
+static void host_resize_coef(int d, double scale, int slen, bool clamp_both, int &s0, int &s1, int &c0, int &c1)
+{
+#pragma clang fp contract(off)
+    const double fd = ((double)d + 0.5) * scale;
+    float f = (float)(fd - 0.5);
+    int s = (int)floorf(f);
+    f = f - (float)s;
+    if (clamp_both) {
+        s0 = s < 0 ? 0 : (s < slen ? s : slen - 1);
+        s1 = s + 1 < 0 ? 0 : (s + 1 < slen ? s + 1 : slen - 1);
+    } else {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= slen - 1) { f = 0.f; s = slen - 1; }
+        s0 = s; s1 = s + 1;
+    }
+    const float g = 1.f - f;
+    c0 = (int)lrintf(g * 2048.f);
+    c1 = (int)lrintf(f * 2048.f);
+}
+static int host_reflect101(int p, int len)
+{
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * (len - 1) - p;
+    return p;
+}
+static void pyr_chunks(PyrLevelTab &T, int rows_per_unit)
+{
+    T.nchunks = (T.words + 63) / 64;
+    T.chunk_w = (T.words + T.nchunks - 1) / T.nchunks;
+    T.rcp_chunks = T.nchunks > 1 ? (uint32_t)(((1ull << 32) + (unsigned)T.nchunks - 1) / (unsigned)T.nchunks) : 0u;
+    T.units = ((T.prows + rows_per_unit - 1) / rows_per_unit) * T.nchunks;
+}
+
+// Row / column tables of k_pyr_base / k_pyr_rows for the bound image size (one device buffer).
+static int build_pyr_tables(orbhip_extractor *e)
+{
+    const PyrGeom &G = e->G;
+    std::vector<uint8_t> blob;
+    auto put = [&blob](const void *p, size_t n) {
+        const size_t at = (blob.size() + 63) & ~(size_t)63;
+        blob.resize(at + n);
+        memcpy(blob.data() + at, p, n);
+        return at;
+    };
+    size_t off_row[ORBHIP_MAX_LEVELS] = {0}, off_col[ORBHIP_MAX_LEVELS] = {0}, off_lo[ORBHIP_MAX_LEVELS] = {0};
+    for (int l = 0; l < G.nlevels; ++l) {
+        const LevelGeom &L = G.lv[l];
+        PyrLevelTab &T = e->ptab[l];
+        memset(&T, 0, sizeof(T));
+        T.prows = L.prows; T.pitch = L.pitch; T.plane_off = L.plane_off;
+        e->ptab_rows[l] = false;
+        if (l == 0) {
+            T.words = L.pitch >> 4;
+            T.src_h = L.h;
+            std::vector<PyrCopyCol> col(T.words);
+            std::vector<uint32_t> lo(T.words);
+            for (int g = 0; g < T.words; ++g) {
+                int rk[16], base = 1 << 30;
+                for (int k = 0; k < 16; ++k) {
+                    const int x = g * 16 - kPadL + k;
+                    rk[k] = (x >= -kEdge && x < L.w + kEdge) ? host_reflect101(x, L.w) : -1;
+                    if (rk[k] >= 0) base = std::min(base, rk[k]);
+                }
+                if (base == (1 << 30)) base = 0;
+                base = std::min(base, L.w - 16);
+                lo[g] = (uint32_t)base;
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t a = 0, b = 0;
+                    for (int k = 0; k < 4; ++k) {
+                        const int idx = rk[4 * j + k] < 0 ? -1 : rk[4 * j + k] - base;
+                        a |= (uint32_t)((idx >= 0 && idx < 8) ? idx : 0x0c) << (8 * k);
+                        b |= (uint32_t)((idx >= 8 && idx < 16) ? idx - 8 : 0x0c) << (8 * k);
+                    }
+                    col[g].selA[j] = a; col[g].selB[j] = b;
+                }
+            }
+            pyr_chunks(T, kPyrRows);
+            off_col[l] = put(col.data(), col.size() * sizeof(PyrCopyCol));
+            off_lo[l] = put(lo.data(), lo.size() * sizeof(uint32_t));
+            e->ptab_rows[l] = true;
+            continue;
+        }
+        const LevelGeom &P = G.lv[l - 1];
+        const double sx = 1. / ((double)L.w / P.w), sy = 1. / ((double)L.h / P.h);   // OpenCV: scale = 1. / ((double)dst / src)
+        T.words = (kPadL + L.w + kEdge + 3) >> 2;
+        T.src_h = P.h; T.src_pitch = P.pitch;
+        T.src_off = P.plane_off + (unsigned)(kEdge * P.pitch + kPadL);
+        std::vector<PyrCol> col(T.words);
+        std::vector<uint32_t> lo(T.words);
+        bool ok = P.w >= 8;
+        for (int pw = 0; pw < T.words && ok; ++pw) {
+            int sxk[4], a0[4], a1[4], lo_ = 1 << 30, hi_ = -1;
+            bool valid[4];
+            for (int k = 0; k < 4; ++k) {
+                const int x = pw * 4 - kPadL + k;
+                valid[k] = x >= -kEdge && x < L.w + kEdge;
+                sxk[k] = 0; a0[k] = a1[k] = 0;
+                if (!valid[k]) continue;
+                int s1;
+                host_resize_coef(host_reflect101(x, L.w), sx, P.w, false, sxk[k], s1, a0[k], a1[k]);
+                lo_ = std::min(lo_, sxk[k]); hi_ = std::max(hi_, sxk[k]);
+            }
+            if (hi_ < 0) { lo_ = 0; hi_ = 0; }
+            if (hi_ - lo_ > 6) { ok = false; break; }
+            lo_ = std::min(lo_, P.w - 8);
+            lo[pw] = (uint32_t)lo_;
+            for (int k = 0; k < 4; ++k) {
+                if (!valid[k]) { col[pw].sel[k] = 0x0c0c0c0cu; col[pw].alv[k] = 0; continue; }
+                const int rel = sxk[k] - lo_;
+                int rel1 = rel + 1;
+                if (sxk[k] + 1 > P.w - 1) { rel1 = rel; if (a1[k] != 0) ok = false; }   // the end column: its second tap has weight 0
+                if (rel < 0 || rel1 > 7) ok = false;
+                col[pw].sel[k] = 0x0c000c00u | (uint32_t)rel | ((uint32_t)rel1 << 16);
+                col[pw].alv[k] = (uint32_t)a0[k] | ((uint32_t)a1[k] << 16);
+            }
+        }
+        if (!ok) continue;   // this level keeps the general kernel
+        std::vector<PyrRow> row(L.prows);
+        for (int py = 0; py < L.prows; ++py) {
+            int s0, s1, b0, b1;
+            host_resize_coef(host_reflect101(py - kEdge, L.h), sy, P.h, true, s0, s1, b0, b1);
+            row[py].s0 = s0; row[py].s1 = s1; row[py].B0 = (uint32_t)b0 << 12; row[py].B1 = (uint32_t)b1 << 12;
+        }
+        pyr_chunks(T, kPyrRows);
+        off_row[l] = put(row.data(), row.size() * sizeof(PyrRow));
+        off_col[l] = put(col.data(), col.size() * sizeof(PyrCol));
+        off_lo[l] = put(lo.data(), lo.size() * sizeof(uint32_t));
+        e->ptab_rows[l] = true;
+    }
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_pyrtab, blob.size() + 64));
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_pyrtab, blob.data(), blob.size(), hipMemcpyHostToDevice, e->stream));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));   // `blob` dies at return
+    for (int l = 0; l < G.nlevels; ++l) {
+        if (!e->ptab_rows[l]) continue;
+        PyrLevelTab &T = e->ptab[l];
+        T.row = reinterpret_cast<const PyrRow *>(e->d_pyrtab + off_row[l]);
+        T.col = e->d_pyrtab + off_col[l];
+        T.lo = reinterpret_cast<const uint32_t *>(e->d_pyrtab + off_lo[l]);
+    }
+    return ORBHIP_OK;
 }
 
 // Bind the handle to an image size: level geometry (:1111-1113), cell table (:769-829),
@@ -1474,6 +1757,7 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
     // uploads go through the handle's own stream (a legacy-stream hipMemcpy would tangle with another host thread's
     // stream capture: the stereo constructor runs two extractors on two threads); the host vectors die at return
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (int rc = build_pyr_tables(e)) return rc;
     e->bound = true;
     return ORBHIP_OK;
 }
@@ -1520,11 +1804,28 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
     if (prof) (void)hipEventRecord(ev[0], s);
     {
-        const LevelGeom &L = G.lv[0];
-        int n = (((L.pitch >> 4) + kL0Q - 1) / kL0Q) * L.prows;
-        hipLaunchKernelGGL(k_pyr_level0, dim3((n + 255) / 256, batch), dim3(256), 0, s, d_images, stride,
-                           frame_stride, b_pyr, G);
-        for (int l = 1; l < G.nlevels; ++l) {
+        static const bool dev_old = getenv("ORBHIP_PYR_GENERAL") != nullptr;   // development switch: the general kernels for every level
+        // level 0 and, when its taps allow, level 1 in one launch
+        const bool l1_rows = G.nlevels > 1 && e->ptab_rows[1] && !dev_old;
+        int first = 1;
+        if (!dev_old) {
+            PyrLevelTab T1 = e->ptab[1];
+            if (!l1_rows) memset(&T1, 0, sizeof(T1));
+            const int nb0 = (e->ptab[0].units + 3) / 4, nb1 = (T1.units + 3) / 4;
+            hipLaunchKernelGGL(k_pyr_base, dim3(nb0 + nb1, batch), dim3(256), 0, s, d_images, stride, frame_stride, b_pyr,
+                               G.frame_bytes, e->ptab[0], T1, nb0);
+            if (l1_rows) first = 2;
+        } else {
+            const LevelGeom &L = G.lv[0];
+            int n = (((L.pitch >> 4) + kL0Q - 1) / kL0Q) * L.prows;
+            hipLaunchKernelGGL(k_pyr_level0, dim3((n + 255) / 256, batch), dim3(256), 0, s, d_images, stride,
+                               frame_stride, b_pyr, G);
+        }
+        for (int l = first; l < G.nlevels; ++l) {
+            if (e->ptab_rows[l] && !dev_old) {
+                hipLaunchKernelGGL(k_pyr_rows, dim3((e->ptab[l].units + 3) / 4, batch), dim3(256), 0, s, b_pyr, G.frame_bytes, e->ptab[l]);
+                continue;
+            }
             const LevelGeom &Ll = G.lv[l];
             int nl = (Ll.pitch >> 2) * ((Ll.prows + kPyrRows - 1) / kPyrRows);
             const LevelGeom &Pl = G.lv[l - 1];

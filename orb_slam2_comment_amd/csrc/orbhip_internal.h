@@ -32,6 +32,25 @@ struct FastParams {
 // the 749 disc offsets of IC_Angle, zero padded to 12 x 64 (pixel k of lane l = entry k*64 + l): signed (u, v) and the
 // int16 pairs (pixel 2k | pixel 2k+1 << 16) the moment dot products take
 struct DiscTab { signed char u[768], v[768]; uint32_t u2[384], v2[384]; };
+// Tables of the pyramid kernels (k_pyr_base / k_pyr_rows): a wavefront owns kPyrRows padded destination rows (its row
+// records come through scalar loads) and one destination dword (resize) or 16-byte group (level-0 copy) per lane.
+struct PyrRow { int s0, s1; uint32_t B0, B1; };        // source rows of a destination row; Q11 row coefficients << 12
+struct PyrCol { uint32_t sel[4]; uint32_t alv[4]; };   // per destination dword: v_perm selectors of the 4 tap pairs inside the
+                                                       // 8-byte source window; Q11 column coefficients a0 | a1 << 16
+struct PyrCopyCol { uint32_t selA[4], selB[4]; };      // level 0: 16 destination bytes gathered from a 16-byte source window
+struct PyrLevelTab {
+    const PyrRow *row;       // [prows]                      (resize only)
+    const void *col;         // [words] PyrCol / PyrCopyCol
+    const uint32_t *lo;      // [words] first source byte of the lane's window
+    int words;               // lanes per padded row: dwords (resize) or 16-byte groups (copy)
+    int nchunks, chunk_w;    // a row is split into nchunks runs of chunk_w <= 64 lanes
+    uint32_t rcp_chunks;     // ceil(2^32 / nchunks)
+    int units;               // wavefront work items = row groups x nchunks
+    int prows, pitch;        // destination plane
+    unsigned plane_off;
+    int src_h, src_pitch;    // source: rows (level-0 copy: REFLECT_101 of the row index), pitch for levels >= 2
+    unsigned src_off;        // source ROI inside the frame's pyramid block (levels >= 2)
+};
 }  // namespace orbhip
 
 struct orbhip_extractor {
@@ -70,6 +89,9 @@ struct orbhip_extractor {
     orbhip::DiscTab disc_host;
     int *d_disc_off = nullptr;      // [768] byte offsets of the disc pixels inside the staged 31 x 36-byte LDS tile
     float4 *d_patternf = nullptr;   // rBRIEF pattern as floats: (x0, y0, x1, y1) per test
+    uint8_t *d_pyrtab = nullptr;    // row / column tables of the pyramid kernels
+    orbhip::PyrLevelTab ptab[ORBHIP_MAX_LEVELS];
+    bool ptab_rows[ORBHIP_MAX_LEVELS];   // level goes through the table-driven resize (all its tap windows fit 8 bytes)
 
     // per-batch-capacity buffers
     int batch_cap = 0;

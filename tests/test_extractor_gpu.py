@@ -35,7 +35,8 @@ def test_extract_matches_oracle_stage_by_stage(mods, W, H, nf, seed):
     assert len(kps) >= 0.95 * nf   # textured input fills (nearly) every level quota
 
 
-@pytest.mark.parametrize("scale,nlevels,ini,mn", [(1.2, 4, 20, 7), (1.5, 5, 30, 10), (1.1, 8, 12, 5), (2.0, 3, 20, 7)])
+@pytest.mark.parametrize("scale,nlevels,ini,mn", [(1.2, 4, 20, 7), (1.5, 5, 30, 10), (1.1, 8, 12, 5), (2.0, 3, 20, 7),
+                                                  (2.6, 3, 20, 7)])   # 2.6: tap groups wider than 8 bytes -> the general resize kernel
 def test_other_constructor_arguments(mods, scale, nlevels, ini, mn):
     pkg, O = mods
     img = synth_frame(11, 640, 480)
