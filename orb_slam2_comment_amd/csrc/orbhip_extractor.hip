@@ -1169,6 +1169,20 @@ __global__ __launch_bounds__(T) void k_octree(PyrGeom G, const int *__restrict__
 constexpr int kBIn = kBlurTH + 6;   // staged input rows (64)
 constexpr int kBInW = 18;           // staged dwords per row: tile bytes x0-4 .. x0+67
 
+__device__ __forceinline__ uint32_t mad24u(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// two int16 lanes -> two saturated bytes in the low half
+__device__ __forceinline__ uint32_t sat_pk_u8(uint32_t v)
+{
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                               PyrGeom G, const TileDesc *__restrict__ tiles, BlurW W)
 {
@@ -1202,32 +1216,38 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
             if (i < nin * kBInW) sin[i] = v[u];
         }
     }
-    const uint32_t wlo = (uint32_t)W.w[0] | ((uint32_t)W.w[1] << 8) | ((uint32_t)W.w[2] << 16) | ((uint32_t)W.w[3] << 24);
-    const uint32_t whi = (uint32_t)W.w[4] | ((uint32_t)W.w[5] << 8) | ((uint32_t)W.w[6] << 16);
+    // row pass: item = (pair-row, 4-px group).  Output j of a group needs tile bytes 4g+1+j .. 4g+7+j, i.e. a window that
+    // starts 1 + j bytes into three consecutive dwords: instead of aligning the data, the taps are laid against the
+    // dwords (ten wave-uniform weight words), 10 v_dot4_u32_u8 per 4 pixels
+    const uint32_t B0 = W.w[0], B1 = W.w[1], B2 = W.w[2], B3 = W.w[3], B4 = W.w[4], B5 = W.w[5], B6 = W.w[6];
+    const uint32_t k0a = (B0 << 8) | (B1 << 16) | (B2 << 24), k0b = B3 | (B4 << 8) | (B5 << 16) | (B6 << 24);
+    const uint32_t k1a = (B0 << 16) | (B1 << 24), k1b = B2 | (B3 << 8) | (B4 << 16) | (B5 << 24), k1c = B6;
+    const uint32_t k2a = B0 << 24, k2b = B1 | (B2 << 8) | (B3 << 16) | (B4 << 24), k2c = B5 | (B6 << 8);
+    const uint32_t k3b = B0 | (B1 << 8) | (B2 << 16) | (B3 << 24), k3c = B4 | (B5 << 8) | (B6 << 16);
     __syncthreads();
-    // row pass: item = (pair-row, 4-px group)
     for (int it = tid; it < npair * 16; it += 256) {
         const int pr = it >> 4, g = it & 15;
         uint32_t s[2][4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const uint32_t *p = &sin[min(2 * pr + h, nin - 1) * kBInW + g];
+            const uint32_t *p = &sin[madi24(min(2 * pr + h, nin - 1), kBInW, g)];
             const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-            // output j needs tile bytes 4g+1+j .. 4g+7+j
-            s[h][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), wlo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), whi, 0, false), false);
-            s[h][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), wlo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), whi, 0, false), false);
-            s[h][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), wlo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), whi, 0, false), false);
-            s[h][3] = __builtin_amdgcn_udot4(d1, wlo, __builtin_amdgcn_udot4(d2, whi, 0, false), false);
+            s[h][0] = __builtin_amdgcn_udot4(d0, k0a, __builtin_amdgcn_udot4(d1, k0b, 0, false), false);
+            s[h][1] = __builtin_amdgcn_udot4(d0, k1a, __builtin_amdgcn_udot4(d1, k1b, __builtin_amdgcn_udot4(d2, k1c, 0, false), false), false);
+            s[h][2] = __builtin_amdgcn_udot4(d0, k2a, __builtin_amdgcn_udot4(d1, k2b, __builtin_amdgcn_udot4(d2, k2c, 0, false), false), false);
+            s[h][3] = __builtin_amdgcn_udot4(d1, k3b, __builtin_amdgcn_udot4(d2, k3c, 0, false), false);
         }
-        srow[it] = make_uint4(s[0][0] | (s[1][0] << 16), s[0][1] | (s[1][1] << 16), s[0][2] | (s[1][2] << 16),
-                              s[0][3] | (s[1][3] << 16));
+        // both sums fit uint16 (<= 255 * 257): one v_perm_b32 interleaves the two rows
+        srow[it] = make_uint4(__builtin_amdgcn_perm(s[1][0], s[0][0], 0x05040100u), __builtin_amdgcn_perm(s[1][1], s[0][1], 0x05040100u),
+                              __builtin_amdgcn_perm(s[1][2], s[0][2], 0x05040100u), __builtin_amdgcn_perm(s[1][3], s[0][3], 0x05040100u));
     }
     __syncthreads();
     // column pass: item = (output row pair, group).  Rows 2p and 2p+1 read the same four staged pair-rows: the even
     // row pairs the taps (w0,w1)(w2,w3)(w4,w5)+w6 with them, the odd row w0+(w1,w2)(w3,w4)(w5,w6).
     const uint32_t w01 = (uint32_t)W.w[0] | ((uint32_t)W.w[1] << 16), w23 = (uint32_t)W.w[2] | ((uint32_t)W.w[3] << 16),
                    w45 = (uint32_t)W.w[4] | ((uint32_t)W.w[5] << 16), w12 = (uint32_t)W.w[1] | ((uint32_t)W.w[2] << 16),
-                   w34 = (uint32_t)W.w[3] | ((uint32_t)W.w[4] << 16), w56 = (uint32_t)W.w[5] | ((uint32_t)W.w[6] << 16);
+                   w34 = (uint32_t)W.w[3] | ((uint32_t)W.w[4] << 16), w56 = (uint32_t)W.w[5] | ((uint32_t)W.w[6] << 16),
+                   w6l = (uint32_t)W.w[6], w0h = (uint32_t)W.w[0] << 16;   // single taps: the other uint16 lane gets weight 0
     const int nprow = (rows + 1) >> 1;
     for (int it = tid; it < nprow * 16; it += 256) {
         const int p = it >> 4, g = it & 15;
@@ -1235,14 +1255,18 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         const uint4 P0 = srow[p * 16 + g], P1 = srow[(p + 1) * 16 + g], P2 = srow[(p + 2) * 16 + g], P3 = srow[(p + 3) * 16 + g];
         const uint32_t a0[4] = {P0.x, P0.y, P0.z, P0.w}, a1[4] = {P1.x, P1.y, P1.z, P1.w},
                        a2[4] = {P2.x, P2.y, P2.z, P2.w}, a3[4] = {P3.x, P3.y, P3.z, P3.w};
-        uint32_t rese = 0, reso = 0;
+        // acc + 2^15 (the rounding term rides in the multiply-add); the result is its upper half, <= 257 (the taps sum
+        // to 257): v_perm_b32 packs two upper halves into one dword and v_sat_pk_u8_i16 saturates both to bytes
+        uint32_t acce[4], acco[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t acce = udot2(a0[j], w01, udot2(a1[j], w23, udot2(a2[j], w45, __umul24(a3[j] & 0xffffu, (uint32_t)W.w[6]))));
-            const uint32_t acco = udot2(a1[j], w12, udot2(a2[j], w34, udot2(a3[j], w56, __umul24(a0[j] >> 16, (uint32_t)W.w[0]))));
-            rese |= min((acce + 32768u) >> 16, 255u) << (8 * j);
-            reso |= min((acco + 32768u) >> 16, 255u) << (8 * j);
+            acce[j] = udot2(a0[j], w01, udot2(a1[j], w23, udot2(a2[j], w45, udot2(a3[j], w6l, 32768u))));
+            acco[j] = udot2(a1[j], w12, udot2(a2[j], w34, udot2(a3[j], w56, udot2(a0[j], w0h, 32768u))));
         }
+        const uint32_t rese = sat_pk_u8(__builtin_amdgcn_perm(acce[1], acce[0], 0x07060302u)) |
+                              (sat_pk_u8(__builtin_amdgcn_perm(acce[3], acce[2], 0x07060302u)) << 16);
+        const uint32_t reso = sat_pk_u8(__builtin_amdgcn_perm(acco[1], acco[0], 0x07060302u)) |
+                              (sat_pk_u8(__builtin_amdgcn_perm(acco[3], acco[2], 0x07060302u)) << 16);
         uint8_t *o = out + (uint32_t)(__mul24(y0 + 2 * p, L.pitch) + x0 + 4 * g);
         *reinterpret_cast<uint32_t *>(o) = rese;
         if (2 * p + 1 < rows) *reinterpret_cast<uint32_t *>(o + L.pitch) = reso;
@@ -1403,6 +1427,200 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, bsn)));
         t0v[j] = cb[__mul24(r0, kPatchDw * 4) + c0];
         t1v[j] = cb[__mul24(r1, kPatchDw * 4) + c1];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bits[j] = __ballot(t0v[j] < t1v[j]);
+    if (lane < 4) {
+        unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        reinterpret_cast<unsigned long long *>(out_desc + ((size_t)b * cap + oidx) * 32)[lane] = v;
+    }
+    if (lane == 0) {
+        orbhip_keypoint kp;
+        float fx = (float)kx, fy = (float)ky;
+        const float scale = G.lv[level].scale;
+        if (level != 0) { fx = __fmul_rn(fx, scale); fy = __fmul_rn(fy, scale); }
+        kp.x = fx; kp.y = fy; kp.size = (float)G.lv[level].patch; kp.angle = angle; kp.response = (float)resp;
+        kp.octave = level; kp.class_id = -1;
+        out_kp[(size_t)b * cap + oidx] = kp;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K5+K6+K7 fused: IC_Angle + GaussianBlur(7x7) of the patch + steered rBRIEF, one wavefront per keypoint.
+// The blurred level is only ever read inside the 37 x 37 patch of a keypoint (:108-147), so the wavefront blurs that
+// patch itself instead of reading a blurred plane that a separate kernel wrote for the whole level:
+//  * ONE staged tile: the 43 x 44-byte window (rows ky-21 .. ky+21, bytes kx-21 .. kx+22) of the unblurred padded
+//    plane, byte-unaligned dword loads so that window column 0 is byte 0 of every row; it holds the 31 x 31
+//    orientation disc and every tap of the patch's blur (the 19-px REFLECT_101 frame covers the 2 px a keypoint at
+//    the minimum border distance reaches outside the level);
+//  * moments from the tile as before (12 disc pixels per lane, v_dot2_i32_i16);
+//  * row pass: item = (pair of window rows, 4 columns); the taps are laid against the three dwords an output group
+//    touches (10 v_dot4_u32_u8 per 4 outputs), the uint16 sums of the two rows go interleaved into one dword;
+//  * column pass: item = (pair of patch rows, 4 columns): 4 v_dot2_u32_u16 per output (rounding term in the
+//    accumulator), v_perm_b32 + v_sat_pk_u8_i16 pack; the blurred patch overwrites the window tile;
+//  * descriptor tests sample the blurred patch in LDS.
+// Same arithmetic as k_blur (which remains for orbhip_blurred_level_download): integer, exact.
+// ---------------------------------------------------------------------------
+constexpr int kWinRows = 43, kWinDw = 11;     // staged window
+constexpr int kWinRpi = 5;                    // rows per staging instruction (55 of 64 lanes)
+constexpr int kWinLoads = 9;                  // 9 x 5 = 45 >= 43 rows
+constexpr int kWinWords = kWinRows * kWinDw + 7;   // + the dwords the last column group reads past the last row
+constexpr int kHPairs = 22, kHGroups = 10;    // row-pass results: 22 pair-rows x 10 groups of 4 columns (uint4 each)
+constexpr int kBPairs = 19, kBDw = 10;        // blurred patch: 38 rows (37 used) x 40 bytes
+
+__global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restrict__ pyr, PyrGeom G,
+                                                        const uint32_t *__restrict__ sel_kp,
+                                                        const int *__restrict__ sel_cnt,
+                                                        const DiscTab *__restrict__ disc,
+                                                        const int *__restrict__ disc_off,
+                                                        const float4 *__restrict__ patternf,
+                                                        orbhip_keypoint *__restrict__ out_kp,
+                                                        uint8_t *__restrict__ out_desc, int cap,
+                                                        int *__restrict__ out_n, int *__restrict__ status, int per_wave, BlurW W)
+{
+    __shared__ uint32_t swin[4][kWinWords];
+    __shared__ uint4 shsum[4][kHPairs * kHGroups];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bx, b;
+    xcd_remap(bx, b);
+    uint32_t u2[6], v2[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { u2[k] = disc->u2[k * 64 + lane]; v2[k] = disc->v2[k * 64 + lane]; }
+    float4 pat[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pat[j] = patternf[j * 64 + lane];
+    int dl[12];   // byte offset of this lane's 12 disc pixels inside the window tile: (v + 21) * 44 + (u + 21)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) dl[k] = disc_off[k * 64 + lane];
+    const int *cnts = sel_cnt + b * ORBHIP_MAX_LEVELS;
+    int total = 0;
+    for (int l = 0; l < G.nlevels; ++l) total += cnts[l];
+    if (bx == 0 && wv == 0 && lane == 0) {
+        out_n[b] = min(total, cap);
+        if (total > cap && status) atomicExch(&status[b], ORBHIP_E_CAPACITY);
+    }
+    // tap words of the row pass (output j of a group starts j bytes into dword 0) and of the column pass
+    const uint32_t B0 = W.w[0], B1 = W.w[1], B2 = W.w[2], B3 = W.w[3], B4 = W.w[4], B5 = W.w[5], B6 = W.w[6];
+    const uint32_t h0a = B0 | (B1 << 8) | (B2 << 16) | (B3 << 24), h0b = B4 | (B5 << 8) | (B6 << 16);
+    const uint32_t h1a = (B0 << 8) | (B1 << 16) | (B2 << 24), h1b = B3 | (B4 << 8) | (B5 << 16) | (B6 << 24);
+    const uint32_t h2a = (B0 << 16) | (B1 << 24), h2b = B2 | (B3 << 8) | (B4 << 16) | (B5 << 24), h2c = B6;
+    const uint32_t h3a = B0 << 24, h3b = B1 | (B2 << 8) | (B3 << 16) | (B4 << 24), h3c = B5 | (B6 << 8);
+    const uint32_t w01 = B0 | (B1 << 16), w23 = B2 | (B3 << 16), w45 = B4 | (B5 << 16), w12 = B1 | (B2 << 16),
+                   w34 = B3 | (B4 << 16), w56 = B5 | (B6 << 16), w6l = B6, w0h = B0 << 16;
+    const int srow = (lane * 373) >> 12, scol = lane - srow * kWinDw;   // lane / 11 for lane < 64; lanes 55..63 idle
+    uint32_t *win = swin[wv];
+    uint4 *hs = shsum[wv];
+  for (int kk = 0; kk < per_wave; ++kk) {
+    const int slot = (bx * 4 + wv) * per_wave + kk;  // wave-uniform: everything up to the pixel loads is scalar work
+    if (slot >= G.kp_cap_total) break;
+    int level = 0;
+    for (int l = 1; l < G.nlevels; ++l) if (slot >= G.lv[l].kp_base) level = l;
+    int before = 0, mine = 0;
+    for (int l = 0; l < G.nlevels; ++l) {
+        const int c = cnts[l];
+        if (l < level) before += c;
+        if (l == level) mine = c;
+    }
+    const int kp_base = G.lv[level].kp_base, pitch = G.lv[level].pitch;
+    const int i = slot - kp_base;
+    if (i >= mine) continue;
+    const int oidx = before + i;
+    if (oidx >= cap) continue;
+
+    const uint32_t kv = sel_kp[(size_t)b * G.kp_cap_total + slot];
+    const int kx = (int)(kv & 0xfff) + 16, ky = (int)((kv >> 12) & 0xfff) + 16;  // + minBorder (:843-844)
+    const int resp = (int)(kv >> 24);
+    const size_t fo = (size_t)b * G.frame_bytes + G.lv[level].plane_off + (size_t)kEdge * pitch + kPadL;
+    const uint8_t *wb = pyr + fo + (size_t)(ky - 21) * pitch + (kx - 21);   // window byte (0, 0), uniform
+    uint32_t wvv[kWinLoads];
+    {
+        const uint32_t voff = (uint32_t)(__mul24(srow, pitch) + 4 * scol);
+#pragma unroll
+        for (int u = 0; u < kWinLoads; ++u) {
+            wvv[u] = 0u;
+            if (lane < kWinRpi * kWinDw && (u < kWinLoads - 1 || srow < kWinRows - (kWinLoads - 1) * kWinRpi))
+                __builtin_memcpy(&wvv[u], wb + (uint32_t)(u * kWinRpi * pitch) + voff, 4);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                     // the previous keypoint's LDS reads are done
+    if (lane < kWinRpi * kWinDw) {
+        uint32_t *dd = win + (srow * kWinDw + scol);
+#pragma unroll
+        for (int u = 0; u < kWinLoads; ++u)
+            if (u < kWinLoads - 1 || srow < kWinRows - (kWinLoads - 1) * kWinRpi) dd[u * kWinRpi * kWinDw] = wvv[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- moments ----
+    int m10 = 0, m01 = 0;
+    {
+        const uint8_t *d8 = reinterpret_cast<const uint8_t *>(win);
+        int pix[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pix[k] = d8[dl[k]];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const uint32_t p2 = (uint32_t)pix[2 * k] | ((uint32_t)pix[2 * k + 1] << 16);
+            m10 = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, p2), __builtin_bit_cast(i16x2_t, u2[k]), m10, false);
+            m01 = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, p2), __builtin_bit_cast(i16x2_t, v2[k]), m01, false);
+        }
+    }
+    // ---- row pass: 7-tap sums of window rows, two rows per item ----
+#pragma unroll 1
+    for (int it = lane; it < kHPairs * kHGroups; it += 64) {
+        const int pr = (it * 205) >> 11, g = it - pr * kHGroups;   // it / 10
+        uint32_t s[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t *p = &win[madi24(min(2 * pr + h, kWinRows - 1), kWinDw, g)];
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            s[h][0] = __builtin_amdgcn_udot4(d0, h0a, __builtin_amdgcn_udot4(d1, h0b, 0, false), false);
+            s[h][1] = __builtin_amdgcn_udot4(d0, h1a, __builtin_amdgcn_udot4(d1, h1b, 0, false), false);
+            s[h][2] = __builtin_amdgcn_udot4(d0, h2a, __builtin_amdgcn_udot4(d1, h2b, __builtin_amdgcn_udot4(d2, h2c, 0, false), false), false);
+            s[h][3] = __builtin_amdgcn_udot4(d0, h3a, __builtin_amdgcn_udot4(d1, h3b, __builtin_amdgcn_udot4(d2, h3c, 0, false), false), false);
+        }
+        hs[it] = make_uint4(__builtin_amdgcn_perm(s[1][0], s[0][0], 0x05040100u), __builtin_amdgcn_perm(s[1][1], s[0][1], 0x05040100u),
+                            __builtin_amdgcn_perm(s[1][2], s[0][2], 0x05040100u), __builtin_amdgcn_perm(s[1][3], s[0][3], 0x05040100u));
+    }
+    m10 = wave_reduce_add(m10);
+    m01 = wave_reduce_add(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, bsn;
+    det_sincos(__fmul_rn(angle, factorPI), &a, &bsn);
+    __builtin_amdgcn_wave_barrier();                     // DS operations of a wavefront execute in order
+    // ---- column pass: blurred patch rows 2p, 2p+1 (patch row r = window rows r .. r+6), written over the window tile ----
+#pragma unroll 1
+    for (int it = lane; it < kBPairs * kBDw; it += 64) {
+        const int p = (it * 205) >> 11, g = it - p * kBDw;
+        const uint4 P0 = hs[p * kHGroups + g], P1 = hs[(p + 1) * kHGroups + g], P2 = hs[(p + 2) * kHGroups + g], P3 = hs[(p + 3) * kHGroups + g];
+        const uint32_t a0[4] = {P0.x, P0.y, P0.z, P0.w}, a1[4] = {P1.x, P1.y, P1.z, P1.w},
+                       a2[4] = {P2.x, P2.y, P2.z, P2.w}, a3[4] = {P3.x, P3.y, P3.z, P3.w};
+        uint32_t acce[4], acco[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acce[j] = udot2(a0[j], w01, udot2(a1[j], w23, udot2(a2[j], w45, udot2(a3[j], w6l, 32768u))));
+            acco[j] = udot2(a1[j], w12, udot2(a2[j], w34, udot2(a3[j], w56, udot2(a0[j], w0h, 32768u))));
+        }
+        win[(2 * p) * kBDw + g] = sat_pk_u8(__builtin_amdgcn_perm(acce[1], acce[0], 0x07060302u)) |
+                                  (sat_pk_u8(__builtin_amdgcn_perm(acce[3], acce[2], 0x07060302u)) << 16);
+        win[(2 * p + 1) * kBDw + g] = sat_pk_u8(__builtin_amdgcn_perm(acco[1], acco[0], 0x07060302u)) |
+                                      (sat_pk_u8(__builtin_amdgcn_perm(acco[3], acco[2], 0x07060302u)) << 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t *cb = reinterpret_cast<const uint8_t *>(win) + 18 * (kBDw * 4) + 18;   // blurred patch byte of the keypoint
+    unsigned long long bits[4];
+    int t0v[4], t1v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float px0 = pat[j].x, py0 = pat[j].y, px1 = pat[j].z, py1 = pat[j].w;
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, bsn), __fmul_rn(py0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, bsn)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, bsn), __fmul_rn(py1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, bsn)));
+        t0v[j] = cb[__mul24(r0, kBDw * 4) + c0];
+        t1v[j] = cb[__mul24(r1, kBDw * 4) + c1];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) bits[j] = __ballot(t0v[j] < t1v[j]);
@@ -1803,7 +2021,8 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     int *status = d_status ? d_status : e->d_status + frame0;
     hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
     if (prof) (void)hipEventRecord(ev[0], s);
-    {
+    const int sm = e->stage_mask;   // development switch (tools/coexec.py): run a subset of the stages on buffers a full run left
+    if (sm & 1) {
         static const bool dev_old = getenv("ORBHIP_PYR_GENERAL") != nullptr;   // development switch: the general kernels for every level
         // level 0 and, when its taps allow, level 1 in one launch
         const bool l1_rows = G.nlevels > 1 && e->ptab_rows[1] && !dev_old;
@@ -1834,7 +2053,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         }
     }
     if (prof) (void)hipEventRecord(ev[1], s);
-    if (G.ncells_total > 0) {
+    if (G.ncells_total > 0 && (sm & 2)) {
         const dim3 grid(G.ncells_total, batch);
         const size_t lb = (size_t)e->fast_lds_bytes;
         FastParams P = e->fast_params;
@@ -1857,7 +2076,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
 #undef ORBHIP_FAST2
     }
     if (prof) (void)hipEventRecord(ev[2], s);
-    {
+    if (sm & 4) {
         const int ot = e->octree_threads;
 #define ORBHIP_OCT(MAXNv, Tv) hipLaunchKernelGGL((k_octree<MAXNv, Tv>), dim3(G.nlevels, batch), dim3(Tv), 0, s, G, b_cell_cnt, b_cell_kp, \
                                                  b_keys, b_knode, b_sel, b_sel_cnt, status)
@@ -1872,15 +2091,22 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     // The blur only needs the pyramid.  Forking it onto a second stream beside FAST/octree was measured: it buys
     // nothing once two pipelines (handles) run concurrently and makes throughput depend on how the runtime maps
     // streams to hardware queues (122 k vs 136 k frames/s run to run), so it stays in order on this stream.
-    hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, b_pyr, b_blur, G,
-                       e->d_tiles, e->blurw);
+    static const bool dev_sep = getenv("ORBHIP_SEPARATE_BLUR") != nullptr;   // development switch: blur kernel + unfused describe
+    if ((sm & 8) && dev_sep) hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, b_pyr, b_blur, G,
+                                                e->d_tiles, e->blurw);
     if (prof) (void)hipEventRecord(ev[4], s);
-    {
+    if (sm & 16) {
         static const int dev_pw = getenv("ORBHIP_DESC_PER_WAVE") ? atoi(getenv("ORBHIP_DESC_PER_WAVE")) : 0;
         const int pw = dev_pw > 0 ? dev_pw : kDescPerWave;
-        hipLaunchKernelGGL(k_orient_describe, dim3((G.kp_cap_total + 4 * pw - 1) / (4 * pw), batch), dim3(256), 0, s, b_pyr, b_blur,
-                           G, b_sel, b_sel_cnt, e->d_disc, e->d_disc_off, e->d_patternf, d_kps, d_desc, cap, d_n, status, pw);
+        const dim3 grid((G.kp_cap_total + 4 * pw - 1) / (4 * pw), batch);
+        if (dev_sep)
+            hipLaunchKernelGGL(k_orient_describe, grid, dim3(256), 0, s, b_pyr, b_blur,
+                               G, b_sel, b_sel_cnt, e->d_disc, e->d_disc_off, e->d_patternf, d_kps, d_desc, cap, d_n, status, pw);
+        else
+            hipLaunchKernelGGL(k_describe_fused, grid, dim3(256), 0, s, b_pyr, G, b_sel, b_sel_cnt, e->d_disc, e->d_disc_off2,
+                               e->d_patternf, d_kps, d_desc, cap, d_n, status, pw, e->blurw);
     }
+    e->blur_valid = dev_sep;
     if (prof) { (void)hipEventRecord(ev[5], s); e->prof_calls++; }
     e->last_batch = frame0 + batch;
     ORBHIP_HIP_CHECK(hipGetLastError());
@@ -1964,12 +2190,15 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
     float patf[1024];
     for (int t = 0; t < 1024; ++t) patf[t] = (float)orbhip_rbrief_pattern[t];
     if (hipMalloc(&e->d_disc, sizeof(DiscTab)) != hipSuccess || hipMalloc(&e->d_patternf, sizeof(patf)) != hipSuccess ||
-        hipMalloc(&e->d_disc_off, 768 * sizeof(int)) != hipSuccess) {
+        hipMalloc(&e->d_disc_off, 768 * sizeof(int)) != hipSuccess || hipMalloc(&e->d_disc_off2, 768 * sizeof(int)) != hipSuccess) {
         set_error("hipMalloc failed"); orbhip_extractor_destroy(e); return ORBHIP_E_HIP;
     }
     int dloff[768];   // byte offset of every disc pixel inside the staged 31 x 36-byte tile; padding entries read (0, 0) with weight 0
     for (int t = 0; t < 768; ++t) dloff[t] = ((int)dv[t] + kHalfPatch) * 36 + ((int)du[t] + kHalfPatch);
+    int dloff2[768];  // the same inside the fused kernel's 43 x 44-byte window tile
+    for (int t = 0; t < 768; ++t) dloff2[t] = ((int)dv[t] + 21) * 44 + ((int)du[t] + 21);
     if (hipMemcpyAsync(e->d_disc_off, dloff, sizeof(dloff), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipMemcpyAsync(e->d_disc_off2, dloff2, sizeof(dloff2), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
         hipMemcpyAsync(e->d_disc, &dt, sizeof(dt), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
         hipMemcpyAsync(e->d_patternf, patf, sizeof(patf), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
         hipStreamSynchronize(e->stream) != hipSuccess) {
@@ -1986,7 +2215,7 @@ void orbhip_extractor_destroy(orbhip_extractor *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_geometry(e);
     free_batch(e);
-    (void)hipFree(e->d_disc); (void)hipFree(e->d_patternf); (void)hipFree(e->d_disc_off); (void)hipFree(e->d_img); (void)hipFree(e->d_okp); (void)hipFree(e->d_odesc); (void)hipFree(e->d_on);
+    (void)hipFree(e->d_disc); (void)hipFree(e->d_patternf); (void)hipFree(e->d_disc_off); (void)hipFree(e->d_disc_off2); (void)hipFree(e->d_img); (void)hipFree(e->d_okp); (void)hipFree(e->d_odesc); (void)hipFree(e->d_on);
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     for (hipEvent_t v : e->ev) (void)hipEventDestroy(v);
@@ -2305,6 +2534,14 @@ int orbhip_pyramid_level_download(orbhip_extractor *e, int frame, int level, int
 
 int orbhip_blurred_level_download(orbhip_extractor *e, int frame, int level, uint8_t *dst, int dst_stride)
 {
+    if (e && e->bound && !e->blur_valid && e->last_batch > 0) {
+        // the pipeline blurs patches inside the descriptor kernel; the full blurred planes are produced on request
+        ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+        hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), e->last_batch), dim3(256), 0, e->stream, e->d_pyr, e->d_blur, e->G,
+                           e->d_tiles, e->blurw);
+        ORBHIP_HIP_CHECK(hipGetLastError());
+        e->blur_valid = true;
+    }
     return download_plane(e, e ? e->d_blur : nullptr, frame, level, 0, dst, dst_stride);
 }
 
@@ -2334,6 +2571,7 @@ int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *
 }
 
 // development switch (not part of include/orbhip.h): 1 = first formulation of the FAST kernel, 0 = current one
+int orbhip_dev_set_stage_mask(orbhip_extractor *e, int mask) { if (!e) return ORBHIP_E_ARG; e->stage_mask = mask; return ORBHIP_OK; }
 int orbhip_dev_set_octree_threads(orbhip_extractor *e, int t) { if (!e) return ORBHIP_E_ARG; e->octree_threads = t; return ORBHIP_OK; }
 int orbhip_dev_set_fast_variant(orbhip_extractor *e, int v)
 {

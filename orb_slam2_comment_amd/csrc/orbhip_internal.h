@@ -79,6 +79,7 @@ struct orbhip_extractor {
     int octree_threads = 256;   // workgroup size of k_octree (256 / 512 / 1024)
     orbhip::FastLds fast_lds;   // k_fast_cells dynamic LDS carve-up
     int fast_lds_bytes = 0;
+    int stage_mask = 31;        // development switch (tools/coexec.py): stages launch_pipeline runs
     int fast_variant = 0;       // development switch (tools/fast_ab.py): 2 stamped build, 3 / 4 timing floors
     orbhip::CellDesc *d_cells = nullptr;
     std::vector<orbhip::FastCell> cells2;
@@ -87,6 +88,8 @@ struct orbhip_extractor {
     orbhip::TileDesc *d_tiles = nullptr;
     orbhip::DiscTab *d_disc = nullptr;
     orbhip::DiscTab disc_host;
+    int *d_disc_off2 = nullptr;     // the same inside the fused descriptor kernel's 43 x 44-byte window tile
+    bool blur_valid = false;        // d_blur holds the blurred planes of the last batch
     int *d_disc_off = nullptr;      // [768] byte offsets of the disc pixels inside the staged 31 x 36-byte LDS tile
     float4 *d_patternf = nullptr;   // rBRIEF pattern as floats: (x0, y0, x1, y1) per test
     uint8_t *d_pyrtab = nullptr;    // row / column tables of the pyramid kernels
