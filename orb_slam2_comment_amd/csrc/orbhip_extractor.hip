@@ -1477,7 +1477,8 @@ __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restric
                                                         const float4 *__restrict__ patternf,
                                                         orbhip_keypoint *__restrict__ out_kp,
                                                         uint8_t *__restrict__ out_desc, int cap,
-                                                        int *__restrict__ out_n, int *__restrict__ status, int per_wave, BlurW W)
+                                                        int *__restrict__ out_n, int *__restrict__ status, int per_wave, BlurW W,
+                                                        const uint32_t *__restrict__ hitem_tab)
 {
     __shared__ uint32_t swin[4][kWinWords];
     __shared__ uint4 shsum[4][kHPairs * kHGroups];
@@ -1510,6 +1511,9 @@ __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restric
     const uint32_t w01 = B0 | (B1 << 16), w23 = B2 | (B3 << 16), w45 = B4 | (B5 << 16), w12 = B1 | (B2 << 16),
                    w34 = B3 | (B4 << 16), w56 = B5 | (B6 << 16), w6l = B6, w0h = B0 << 16;
     const int srow = (lane * 373) >> 12, scol = lane - srow * kWinDw;   // lane / 11 for lane < 64; lanes 55..63 idle
+    // row-pass items of this lane: only the 189 of the 220 (pair-row, group) items that a descriptor test can reach
+    // (rotated pattern offsets stay inside a disc of radius 18.4 + rounding) are computed -- 3 rounds instead of 4
+    const uint32_t hitems = hitem_tab[lane];
     uint32_t *win = swin[wv];
     uint4 *hs = shsum[wv];
   for (int kk = 0; kk < per_wave; ++kk) {
@@ -1568,7 +1572,8 @@ __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restric
     }
     // ---- row pass: 7-tap sums of window rows, two rows per item ----
 #pragma unroll 1
-    for (int it = lane; it < kHPairs * kHGroups; it += 64) {
+    for (int q = 0; q < 3; ++q) {
+        const int it = (int)((hitems >> (8 * q)) & 0xffu);         // this lane's q-th (pair-row, group) item
         const int pr = (it * 205) >> 11, g = it - pr * kHGroups;   // it / 10
         uint32_t s[2][4];
 #pragma unroll
@@ -2104,7 +2109,8 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
                                G, b_sel, b_sel_cnt, e->d_disc, e->d_disc_off, e->d_patternf, d_kps, d_desc, cap, d_n, status, pw);
         else
             hipLaunchKernelGGL(k_describe_fused, grid, dim3(256), 0, s, b_pyr, G, b_sel, b_sel_cnt, e->d_disc, e->d_disc_off2,
-                               e->d_patternf, d_kps, d_desc, cap, d_n, status, pw, e->blurw);
+                               e->d_patternf, d_kps, d_desc, cap, d_n, status, pw, e->blurw,
+                               reinterpret_cast<const uint32_t *>(e->d_disc_off2 + 768));
     }
     e->blur_valid = dev_sep;
     if (prof) { (void)hipEventRecord(ev[5], s); e->prof_calls++; }
@@ -2190,13 +2196,37 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
     float patf[1024];
     for (int t = 0; t < 1024; ++t) patf[t] = (float)orbhip_rbrief_pattern[t];
     if (hipMalloc(&e->d_disc, sizeof(DiscTab)) != hipSuccess || hipMalloc(&e->d_patternf, sizeof(patf)) != hipSuccess ||
-        hipMalloc(&e->d_disc_off, 768 * sizeof(int)) != hipSuccess || hipMalloc(&e->d_disc_off2, 768 * sizeof(int)) != hipSuccess) {
+        hipMalloc(&e->d_disc_off, 768 * sizeof(int)) != hipSuccess || hipMalloc(&e->d_disc_off2, (768 + 64) * sizeof(int)) != hipSuccess) {
         set_error("hipMalloc failed"); orbhip_extractor_destroy(e); return ORBHIP_E_HIP;
     }
     int dloff[768];   // byte offset of every disc pixel inside the staged 31 x 36-byte tile; padding entries read (0, 0) with weight 0
     for (int t = 0; t < 768; ++t) dloff[t] = ((int)dv[t] + kHalfPatch) * 36 + ((int)du[t] + kHalfPatch);
-    int dloff2[768];  // the same inside the fused kernel's 43 x 44-byte window tile
+    int dloff2[768 + 64];  // the same inside the fused kernel's 43 x 44-byte window tile, then the row-pass item table
     for (int t = 0; t < 768; ++t) dloff2[t] = ((int)dv[t] + 21) * 44 + ((int)du[t] + 21);
+    {
+        // A descriptor test samples the blurred patch at (round(x*sin + y*cos), round(x*cos - y*sin)) of a pattern point
+        // (x, y): |offset component| <= round(max radius) and offset length <= max radius + sqrt(0.5).  Patch row r'
+        // (offset r' - 18) needs the row sums of window rows r' .. r' + 6; a row-pass item covers window rows 2pr, 2pr+1
+        // and columns 4g .. 4g+3.
+        double rmax = 0;
+        for (int t = 0; t < 512; ++t) rmax = std::max(rmax, std::hypot((double)orbhip_rbrief_pattern[2 * t], (double)orbhip_rbrief_pattern[2 * t + 1]));
+        const int cmax = (int)floor(rmax + 0.5);
+        const double lim2 = (rmax + 0.7072) * (rmax + 0.7072);
+        bool need[22 * 10] = {false};
+        if (cmax > 18) { set_error("rBRIEF pattern radius exceeds the staged patch"); orbhip_extractor_destroy(e); return ORBHIP_E_ARG; }
+        for (int dy = -cmax; dy <= cmax; ++dy)
+            for (int dx = -cmax; dx <= cmax; ++dx) {
+                if ((double)(dy * dy + dx * dx) > lim2) continue;
+                for (int k = 0; k < 7; ++k) need[((dy + 18 + k) / 2) * 10 + (dx + 18) / 4] = true;
+            }
+        std::vector<int> items;
+        for (int it = 0; it < 220; ++it) if (need[it]) items.push_back(it);
+        if (items.size() > 192) {   // cannot happen for the rBRIEF pattern (189); keep a correct fallback: 4 rounds are not available
+            set_error("row-pass item table overflow (%d)", (int)items.size()); orbhip_extractor_destroy(e); return ORBHIP_E_ARG;
+        }
+        while (items.size() < 192) items.push_back(items[0]);   // idle slots repeat an item (same value written twice)
+        for (int l = 0; l < 64; ++l) dloff2[768 + l] = items[l] | (items[64 + l] << 8) | (items[128 + l] << 16);
+    }
     if (hipMemcpyAsync(e->d_disc_off, dloff, sizeof(dloff), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
         hipMemcpyAsync(e->d_disc_off2, dloff2, sizeof(dloff2), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
         hipMemcpyAsync(e->d_disc, &dt, sizeof(dt), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
