@@ -747,16 +747,23 @@ __device__ __forceinline__ void pick2(const unsigned long long *list, unsigned l
 
 __device__ __forceinline__ void three_maxima(const int *h, int &ind1, int &ind2, int &ind3)
 {
-    int max1 = 0, max2 = 0, max3 = 0;
-    ind1 = ind2 = ind3 = -1;
+    // ComputeThreeMaxima (src/ORBmatcher.cc:1601-1645) as selects on values: with the three indices passed by reference
+    // through a chain of branches the compiler kept them in scratch memory (150 scratch accesses per call)
+    int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+    int hv[HISTO_LENGTH];   // all bins first (independent loads, one wait), then the scan on registers
+#pragma unroll
+    for (int i = 0; i < HISTO_LENGTH; ++i) hv[i] = h[i];
+#pragma unroll
     for (int i = 0; i < HISTO_LENGTH; ++i) {
-        const int s = h[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-        else if (s > max3) { max3 = s; ind3 = i; }
+        const int s = hv[i];
+        const bool g1 = s > max1, g2 = s > max2, g3 = s > max3;
+        max3 = g2 ? max2 : (g3 ? s : max3);  i3 = g2 ? i2 : (g3 ? i : i3);
+        max2 = g1 ? max1 : (g2 ? s : max2);  i2 = g1 ? i1 : (g2 ? i : i2);
+        max1 = g1 ? s : max1;                i1 = g1 ? i : i1;
     }
-    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
-    else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+    else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+    ind1 = i1; ind2 = i2; ind3 = i3;
 }
 
 __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbhip_keypoint *__restrict__ qkeys,
@@ -898,34 +905,47 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
 
 // ---- parallel resolve: modes 0 / 1 (SearchByProjection overloads) and 4 (SearchForTriangulation: one pre-gated
 // candidate per query, no blocking, rotation cull, output per query) ---------------------------------------------
-// The sequential reference loop is the unique solution of
-//   choice(i) = first candidate of query i (in (distance, visiting order)) that is neither taken on entry
-//               nor chosen by an accepted, observed query j < i,
-// so it can be found by fixed-point iteration: every round all queries re-pick in parallel against the
-// owners (smallest accepted observed query per slot) of the previous round; query i is final once all
-// j < i are, so at most nq+1 rounds are needed and typically 3-5.  One workgroup, state in LDS.
+// The sequential reference loop hands every query, in index order, the first candidate of its list (sorted by
+// (distance, visiting order)) that is neither taken on entry nor already held by an accepted, observed query with a
+// smaller index.  That is serial dictatorship, and its outcome is the unique stable matching of "queries prefer list
+// order, slots prefer the smaller query index", which deferred acceptance reaches from any proposal order: every round
+// all unsettled queries propose (atomicMin on the slot's holder) to the first entry of their list that no smaller query
+// holds.  A slot's holder only ever gets smaller and nobody gives a slot up voluntarily (a larger distance only lowers
+// the chance of acceptance; for the ratio test of mode 1 the second candidate only moves away, which can turn a
+// rejection into an acceptance but never the reverse), so each query's list cursor is monotone: the total walk is the
+// list length, not list length x rounds.  One workgroup per pair, state in LDS, one barrier per round.
 // State of the parallel resolve.  Up to kResolveMax train keypoints and queries it lives in LDS (GS = false); beyond
 // that the same arrays are carved out of an HBM workspace (GS = true: same code, global loads / atomics).
 struct ResolveParState {
-    int *owner[2];                       // smallest accepted+observed query that picks the slot (ping-pong)
+    int *owner[2];                       // [0]: holder of every slot (smallest accepted, observed proposer); [1]: cursors
     int *choice;                         // slot picked by query i, -1 if none accepted
     float *t_angle, *q_angle;
     unsigned char *t_oct, *q_obs, *taken, *evbin;
     int *hist;                           // HISTO_LENGTH bins
-    int *vars;                           // changed, nacc, ncull
+    int *vars;                           // [0], [3], [4]: rotating "a choice changed" flags; [1] accepted; [2] culled
+    unsigned short *cur1, *cur2;         // per query: first list entry not known to be unavailable (best / second best)
+    unsigned short *wl[2];               // work lists of the event-driven rounds (queries to step next)
+    uint32_t *lc;                        // first lcn entries of every query's sorted list as (distance << 20 | slot), row
+    int lcn;                             // stride lcn + 1: the steps re-read list heads and must not wait for HBM
 };
-__host__ __device__ inline size_t resolve_par_bytes(size_t n, size_t nq)
+constexpr int kResolveLdsBudget = 156 * 1024;   // dynamic LDS the LDS variant may ask for (160 KB per CU)
+constexpr int kResolveHead = 16;
+__host__ __device__ inline size_t resolve_par_bytes(size_t n, size_t nq, size_t lcn = 0)
 {
     n = (n + 3) & ~(size_t)3; nq = (nq + 3) & ~(size_t)3;
-    return (2 * n + nq + n + nq) * 4 + 2 * n + 2 * nq + (HISTO_LENGTH + 2 + 4) * 4;
+    return (2 * n + nq + n + nq) * 4 + 2 * n + 2 * nq + (HISTO_LENGTH + 2 + 16) * 4 + 8 * nq + (lcn ? nq * (lcn + 1) * 4 : 0);
 }
-__device__ __forceinline__ void resolve_par_carve(ResolveParState &S, unsigned char *base, size_t n, size_t nq)
+__device__ __forceinline__ void resolve_par_carve(ResolveParState &S, unsigned char *base, size_t n, size_t nq, int lcn = 0)
 {
     n = (n + 3) & ~(size_t)3; nq = (nq + 3) & ~(size_t)3;
+    S.lcn = lcn;
+    S.lc = reinterpret_cast<uint32_t *>(base + resolve_par_bytes(n, nq, 0));
     int *p = reinterpret_cast<int *>(base);
     S.owner[0] = p; p += n; S.owner[1] = p; p += n; S.choice = p; p += nq;
     S.t_angle = reinterpret_cast<float *>(p); p += n; S.q_angle = reinterpret_cast<float *>(p); p += nq;
-    S.hist = p; p += HISTO_LENGTH + 2; S.vars = p; p += 4;
+    S.hist = p; p += HISTO_LENGTH + 2; S.vars = p; p += 16;
+    S.cur1 = reinterpret_cast<unsigned short *>(p); S.cur2 = S.cur1 + nq; p += nq;
+    S.wl[0] = reinterpret_cast<unsigned short *>(p); S.wl[1] = S.wl[0] + nq; p += nq;
     unsigned char *c = reinterpret_cast<unsigned char *>(p);
     S.t_oct = c; c += n; S.taken = c; c += n; S.q_obs = c; c += nq; S.evbin = c;
 }
@@ -939,7 +959,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                                                       const uint8_t *__restrict__ taken_in, float nnratio,
                                                       int check_ori, int *__restrict__ out, int *__restrict__ out_n, Batch B,
                                                       int th_accept, int all_block, unsigned char *__restrict__ gstate,
-                                                      size_t gstate_stride)
+                                                      size_t gstate_stride, int n_alloc, int nq_alloc, int lcn)
 {
     extern __shared__ unsigned char resolve_lds[];
     const int tid = threadIdx.x, T = blockDim.x;
@@ -958,12 +978,11 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     const int n = F.n;
     ResolveParState S;
     if (GS) resolve_par_carve(S, gstate + (size_t)blockIdx.x * gstate_stride, (size_t)n, (size_t)nq);
-    else resolve_par_carve(S, resolve_lds, kResolveMax, kResolveMax);
-    // ping-pong owner arrays as two named pointers that swap every round (indexing S.owner[] with a run-time value would
-    // put the whole state struct into scratch memory)
-    int *own_cur = S.owner[0], *own_nxt = S.owner[1];
+    else resolve_par_carve(S, resolve_lds, (size_t)n_alloc, (size_t)nq_alloc, lcn);
+    int *holder = S.owner[0];
+    unsigned short *cur1 = S.cur1, *cur2 = S.cur2;
     for (int i = tid; i < n; i += T) {
-        own_cur[i] = INT_MAX;
+        holder[i] = INT_MAX;
         S.taken[i] = (unsigned char)(taken_in ? taken_in[i] != 0 : 0);
         S.t_angle[i] = F.keys[i].angle;
         S.t_oct[i] = (unsigned char)F.keys[i].octave;
@@ -973,95 +992,185 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
         S.q_angle[i] = q[i].angle;
         S.q_obs[i] = (unsigned char)(all_block || q[i].observed != 0);
         S.evbin[i] = 0xff;
+        cur1[i] = 0; cur2[i] = 0;
     }
     if (tid < HISTO_LENGTH) S.hist[tid] = 0;
-    if (tid == 0) { S.vars[1] = 0; S.vars[2] = 0; }
-    __syncthreads();
-    // the head of this thread's first query list stays in registers: every round re-walks the list, and in the common
-    // case the answer is among its first entries (sorted lists only)
-    constexpr int kHead = 4;
-    unsigned long long head[kHead];
-    int head_c = 0;
-    if (tid < nq) {
-        head_c = cnt[tid];
-        if (head_c > 0) {
-            const unsigned long long *l0 = ccand ? ccand + (size_t)tid * kCompact : cand + (size_t)tid * stride;
-#pragma unroll
-            for (int e = 0; e < kHead; ++e) head[e] = e < head_c ? l0[e] : ~0ull;
-        }
-    }
-    for (int round = 0; round <= nq + 1; ++round) {
-        if (tid == 0) S.vars[0] = 0;
-        for (int c = tid; c < n; c += T) own_nxt[c] = INT_MAX;
-        __syncthreads();
+    if (tid < 16) S.vars[tid] = 0;
+    // the head of every sorted list goes to LDS (all loads of a thread are issued together)
+    int head_c = tid < nq ? cnt[tid] : 0;
+    if (!GS && S.lcn > 0) {
         for (int i = tid; i < nq; i += T) {
             const int c = i == tid ? head_c : cnt[i];
-            int newc = -1;
-            if (c != 0) {
-                const unsigned long long *list = (c > 0 && ccand) ? ccand + (size_t)i * kCompact : cand + (size_t)i * stride;
-                unsigned long long k1 = ~0ull, k2 = ~0ull;
-                if (c > 0) {   // sorted: walk until two usable candidates are found
-                    for (int e = 0; e < c; ++e) {
-                        unsigned long long v;
-                        if (i == tid && e < kHead) v = e == 0 ? head[0] : e == 1 ? head[1] : e == 2 ? head[2] : head[3];
-                        else v = list[e];
-                        const int idx = (int)(v & 0xfffffu);
-                        if (S.taken[idx] || own_cur[idx] < i) continue;
-                        if (k1 == ~0ull) { k1 = v; if (mode == 0 || mode == 4) break; }
-                        else { k2 = v; break; }
-                    }
-                } else {       // unsorted: smallest and second smallest usable key
-                    for (int e = 0; e < -c; ++e) {
-                        const unsigned long long v = list[e];
-                        const int idx = (int)(v & 0xfffffu);
-                        if (S.taken[idx] || own_cur[idx] < i) continue;
-                        if (v < k1) { k2 = k1; k1 = v; } else if (v < k2) k2 = v;
-                    }
-                }
-                if (k1 != ~0ull) {
-                    const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xfffffu);
-                    bool acc = bestDist <= th_accept;
-                    if (acc && mode == 1) {
-                        const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
-                        const int bestLevel = S.t_oct[bestIdx];
-                        const int bestLevel2 = k2 == ~0ull ? -1 : (int)S.t_oct[(int)(k2 & 0xfffffu)];
-                        if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) acc = false;
-                    }
-                    if (acc) newc = bestIdx;
-                }
-            }
-            if (newc != S.choice[i]) { S.choice[i] = newc; S.vars[0] = 1; }
-            if (newc >= 0 && S.q_obs[i]) atomicMin(&own_nxt[newc], i);
-        }
-        __syncthreads();
-        { int *t_ = own_cur; own_cur = own_nxt; own_nxt = t_; }
-        const int changed = S.vars[0];
-        __syncthreads();
-        if (!changed) {
-            if (tid == 0) { atomicAdd(&g_resolve_stats[0], 1u); atomicAdd(&g_resolve_stats[1], (unsigned)round + 1); atomicMax(&g_resolve_stats[2], (unsigned)round + 1); }
-            break;
+            if (c <= 0) continue;
+            const unsigned long long *l0 = ccand ? ccand + (size_t)i * kCompact : cand + (size_t)i * stride;
+            unsigned long long v[kResolveHead];
+#pragma unroll
+            for (int e = 0; e < kResolveHead; ++e) v[e] = (e < c && e < S.lcn) ? l0[e] : ~0ull;
+#pragma unroll
+            for (int e = 0; e < kResolveHead; ++e)
+                if (e < c && e < S.lcn) S.lc[i * (S.lcn + 1) + e] = ((uint32_t)(v[e] >> 32) << 20) | (uint32_t)(v[e] & 0xfffffu);
         }
     }
+    __syncthreads();
+    // One deferred-acceptance step of query i against the holders as they are right now (any interleaving of proposals
+    // is a valid execution, the atomics are the only synchronisation the matching needs).  Returns "the choice changed".
+    auto held_by_smaller = [&](int idx, int i) -> bool {
+        return S.taken[idx] || __hip_atomic_load(&holder[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i;
+    };
+    unsigned short *wl_next = nullptr;   // set by the event-driven rounds
+    int *wl_count = nullptr;
+    auto step = [&](int i) -> bool {
+        const int c = i == tid ? head_c : cnt[i];
+        int newc = -1;
+        if (c != 0) {
+            const unsigned long long *list = (c > 0 && ccand) ? ccand + (size_t)i * kCompact : cand + (size_t)i * stride;
+            unsigned long long k1 = ~0ull, k2 = ~0ull;
+            if (c > 0) {   // sorted: monotone cursors
+                const uint32_t *lrow = S.lc + i * (S.lcn + 1);
+                auto entry = [&](int e) -> unsigned long long {
+                    if (e >= c) return ~0ull;
+                    if (!GS && e < S.lcn) { const uint32_t w = lrow[e]; return ((unsigned long long)(w >> 20) << 32) | (w & 0xfffffu); }
+                    return list[e];
+                };
+                // four entries per trip: their eight LDS reads (taken, holder) are in flight together
+                int e1 = cur1[i];
+                while (e1 < c) {
+                    const unsigned long long v0 = entry(e1), v1 = entry(e1 + 1), v2 = entry(e1 + 2), v3 = entry(e1 + 3);
+                    const bool a0 = !held_by_smaller((int)(v0 & 0xfffffu), i);
+                    const bool a1 = v1 != ~0ull && !held_by_smaller((int)(v1 & 0xfffffu), i);
+                    const bool a2 = v2 != ~0ull && !held_by_smaller((int)(v2 & 0xfffffu), i);
+                    const bool a3 = v3 != ~0ull && !held_by_smaller((int)(v3 & 0xfffffu), i);
+                    if (a0) { k1 = v0; break; }
+                    if (a1) { k1 = v1; e1 += 1; break; }
+                    if (a2) { k1 = v2; e1 += 2; break; }
+                    if (a3) { k1 = v3; e1 += 3; break; }
+                    e1 += 4;
+                }
+                e1 = min(e1, c);
+                cur1[i] = (unsigned short)e1;
+                if (mode == 1 && e1 < c) {
+                    int e2 = max((int)cur2[i], e1 + 1);
+                    for (; e2 < c; ++e2) {
+                        const unsigned long long v = entry(e2);
+                        if (!held_by_smaller((int)(v & 0xfffffu), i)) { k2 = v; break; }
+                    }
+                    cur2[i] = (unsigned short)e2;
+                }
+            } else {       // unsorted (more than 64 candidates): smallest and second smallest available key
+                for (int e = 0; e < -c; ++e) {
+                    const unsigned long long v = list[e];
+                    if (held_by_smaller((int)(v & 0xfffffu), i)) continue;
+                    if (v < k1) { k2 = k1; k1 = v; } else if (v < k2) k2 = v;
+                }
+            }
+            if (k1 != ~0ull) {
+                const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xfffffu);
+                bool acc = bestDist <= th_accept;
+                if (acc && mode == 1) {
+                    const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
+                    const int bestLevel = S.t_oct[bestIdx];
+                    const int bestLevel2 = k2 == ~0ull ? -1 : (int)S.t_oct[(int)(k2 & 0xfffffu)];
+                    if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) acc = false;
+                }
+                if (acc) newc = bestIdx;
+            }
+        }
+        if (newc == S.choice[i]) return false;
+        S.choice[i] = newc;
+        if (newc >= 0 && S.q_obs[i]) {
+            const int old = atomicMin(&holder[newc], i);
+            // event-driven rounds: whoever loses the slot steps again -- me if a smaller query got there first, the
+            // previous holder if I displaced it
+            if (wl_next) {
+                const int again = old < i ? i : (old != INT_MAX ? old : -1);
+                if (again >= 0) wl_next[atomicAdd(wl_count, 1)] = (unsigned short)again;
+            }
+        }
+        return true;
+    };
+    if (mode != 1) {
+        // Event-driven rounds (no second candidate, so a query's choice can only change when it loses its slot): the
+        // first round steps every query, every later one only the queries the previous round pushed out -- the whole
+        // pair lives on one CU, so the rounds are bound by instruction issue, and the work lists keep most wavefronts
+        // out of them.  Counters vars[5..7] rotate: read / filled / reset.  Queries that do not hold slots
+        // (unobserved) are not told when their pick is taken, they take one more step at the end.
+        int c_in = 5, c_out = 6, c_clr = 7, rounds = 0;
+        unsigned short *w_in = S.wl[0], *w_out = S.wl[1];
+        wl_next = w_out; wl_count = &S.vars[c_out];
+        for (int i = tid; i < nq; i += T) step(i);
+        __syncthreads();
+        for (;; ++rounds) {
+            { unsigned short *t_ = w_in; w_in = w_out; w_out = t_; }
+            { const int t_ = c_in; c_in = c_out; c_out = c_clr; c_clr = t_; }
+            const int nw = S.vars[c_in];
+            if (nw == 0 || rounds > 65 * nq) break;
+            if (tid == 0) S.vars[c_clr] = 0;
+            wl_next = w_out; wl_count = &S.vars[c_out];
+            for (int k = tid; k < nw; k += T) step((int)w_in[k]);
+            __syncthreads();
+        }
+        wl_next = nullptr;
+        bool unobs = false;
+        for (int i = tid; i < nq; i += T) unobs |= !S.q_obs[i];
+        if (__any(unobs))
+            for (int i = tid; i < nq; i += T) if (!S.q_obs[i]) step(i);
+        if (tid == 0) { atomicAdd(&g_resolve_stats[0], 1u); atomicAdd(&g_resolve_stats[1], (unsigned)rounds + 1); atomicMax(&g_resolve_stats[2], (unsigned)rounds + 1); }
+    } else {
+        // mode 1 (second candidate, ratio test): a wavefront keeps stepping its own queries until a step changes none of
+        // them; the barrier only serves the termination test (a round in which no query of the workgroup changed).
+        // Three "changed" flags in rotation (vars[0], [3], [4]): a round raises its own and resets the next one's.
+        constexpr int kLocalSteps = 16;
+        int f_cur = 0, f_nxt = 3;
+        for (int round = 0; round <= 65 * nq + 2; ++round) {   // every round but the last moves at least one cursor
+            int *flag = &S.vars[f_cur];
+            if (tid == 0) S.vars[f_nxt] = 0;
+            bool wave_changed = false;
+            for (int ls = 0; ls < kLocalSteps; ++ls) {
+                bool ch = false;
+                for (int i = tid; i < nq; i += T) ch |= step(i);
+                if (!__any(ch)) break;
+                wave_changed = true;
+            }
+            if (wave_changed && (tid & 63) == 0) *flag = 1;
+            __syncthreads();
+            const int changed = *flag;
+            f_cur = f_nxt; f_nxt = f_nxt == 0 ? 3 : f_nxt == 3 ? 4 : 0;
+            if (!changed) {
+                if (tid == 0) { atomicAdd(&g_resolve_stats[0], 1u); atomicAdd(&g_resolve_stats[1], (unsigned)round + 1); atomicMax(&g_resolve_stats[2], (unsigned)round + 1); }
+                break;
+            }
+        }
+    }
+    __syncthreads();
     // ---- outputs: assign[slot] = last accepted query that picked it; rotation-histogram cull (mode 0) ----
-    int *assign = own_nxt;   // reuse
+    int *assign = S.owner[1];
     for (int c = tid; c < n; c += T) assign[c] = -1;
     __syncthreads();
     int acc_local = 0;
     const bool ori = (mode == 0 || mode == 4) && check_ori;
-    for (int i = tid; i < nq; i += T) {
-        const int c = S.choice[i];
-        if (c < 0) continue;
-        ++acc_local;
-        atomicMax(&assign[c], i);
-        if (ori) {
-            const int bin = rot_bin(S.q_angle[i], S.t_angle[c]);
-            if (bin >= 0) {
-                atomicAdd(&S.hist[bin], 1);
-                S.evbin[i] = (unsigned char)bin;
+    for (int i0 = 0; i0 < nq; i0 += T) {
+        const int i = i0 + tid;
+        const int c = i < nq ? S.choice[i] : -1;
+        int bin = -1;
+        if (c >= 0) {
+            ++acc_local;
+            atomicMax(&assign[c], i);
+            if (ori) {
+                bin = rot_bin(S.q_angle[i], S.t_angle[c]);
+                if (bin >= 0) S.evbin[i] = (unsigned char)bin;
             }
         }
+        // one LDS atomic per distinct bin of the wavefront (most matches of a frame pair share a rotation bin)
+        unsigned long long todo = __ballot(bin >= 0);
+        while (todo) {
+            const int lead = __builtin_amdgcn_readlane(bin, __ffsll((long long)todo) - 1);
+            const unsigned long long same = __ballot(bin == lead);
+            if ((tid & 63) == __ffsll((long long)todo) - 1) atomicAdd(&S.hist[lead], __popcll(same));
+            todo &= ~same;
+        }
     }
-    if (acc_local) atomicAdd(&S.vars[1], acc_local);
+    acc_local = wave_reduce_add_i(acc_local);
+    if ((tid & 63) == 0 && acc_local) atomicAdd(&S.vars[1], acc_local);
     __syncthreads();
     if (ori) {
         int ind1, ind2, ind3;
@@ -1855,7 +1964,7 @@ static int ensure_resolve_attr(orbhip_matcher *m)
         ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)sizeof(ResolveShared)));
         ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_par<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)resolve_par_bytes(kResolveMax, kResolveMax)));
+                                             kResolveLdsBudget));
         m->lds_attr_set = true;
     }
     return ORBHIP_OK;
@@ -1871,16 +1980,20 @@ static int launch_resolve_par(orbhip_matcher *m, int pairs, int mode, const DevF
     static const int dev_threads = getenv("ORBHIP_RESOLVE_THREADS") ? atoi(getenv("ORBHIP_RESOLVE_THREADS")) : 0;
     const int threads = dev_threads ? dev_threads : 1024;
     if (n_train <= kResolveMax && nq <= kResolveMax) {
-        hipLaunchKernelGGL(k_resolve_par<false>, dim3(pairs), dim3(threads), resolve_par_bytes(kResolveMax, kResolveMax), m->stream,
-                           mode, D, d_q, nq, d_cand, d_ccand, d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out_n, B, th_accept,
-                           all_block, (unsigned char *)nullptr, (size_t)0);
+        // LDS state sized by the batch's capacities; the list heads go to LDS when the budget allows
+        const size_t state = resolve_par_bytes((size_t)n_train, (size_t)nq, 0);
+        const int lcn = resolve_par_bytes((size_t)n_train, (size_t)nq, kResolveHead) <= (size_t)kResolveLdsBudget ? kResolveHead : 0;
+        (void)state;
+        hipLaunchKernelGGL(k_resolve_par<false>, dim3(pairs), dim3(threads), resolve_par_bytes((size_t)n_train, (size_t)nq, (size_t)lcn),
+                           m->stream, mode, D, d_q, nq, d_cand, d_ccand, d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out_n, B,
+                           th_accept, all_block, (unsigned char *)nullptr, (size_t)0, n_train, nq, lcn);
     } else {
         const size_t per = al256(resolve_par_bytes((size_t)n_train, (size_t)nq));
         void *p;
         int rc = scratch(m, S_STATE, per * (size_t)pairs, &p);
         if (rc) return rc;
         hipLaunchKernelGGL(k_resolve_par<true>, dim3(pairs), dim3(1024), 0, m->stream, mode, D, d_q, nq, d_cand, d_ccand, d_cnt,
-                           stride, d_taken, nnratio, check_ori, d_out, d_out_n, B, th_accept, all_block, (unsigned char *)p, per);
+                           stride, d_taken, nnratio, check_ori, d_out, d_out_n, B, th_accept, all_block, (unsigned char *)p, per, 0, 0, 0);
     }
     return ORBHIP_OK;
 }
