@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-gpu", type=int, default=128,
-                    help="frames resident in HBM per GPU and step (two 64-frame pipelines by default)")
+                    help="frames resident in HBM per GPU and step (split over --handles pipelines: 44 + 42 + 42 by default)")
     ap.add_argument("--min-time", type=float, default=MIN_TIMED_S,
                     help="minimum length in seconds of every timed region (profiler runs pass 0: one repeat of --steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -206,7 +206,7 @@ def main():
                          "gather run on fabricated result slots; no extraction, no throughput claim")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the multi-rank code path (RCCL init, gather, all_reduce) even with one rank")
-    ap.add_argument("--handles", type=int, default=2,
+    ap.add_argument("--handles", type=int, default=3,
                     help="pipelines per GPU; the per-GPU batch is split evenly between them and they run concurrently "
                          "on separate HIP streams (extractor + matcher handle each)")
     args = ap.parse_args()

@@ -924,16 +924,17 @@ struct ResolveParState {
     int *hist;                           // HISTO_LENGTH bins
     int *vars;                           // [0], [3], [4]: rotating "a choice changed" flags; [1] accepted; [2] culled
     unsigned short *cur1, *cur2;         // per query: first list entry not known to be unavailable (best / second best)
+    int *q_cnt;                          // candidates per query (sign = unsorted)
     unsigned short *wl[2];               // work lists of the event-driven rounds (queries to step next)
     uint32_t *lc;                        // first lcn entries of every query's sorted list as (distance << 20 | slot), row
     int lcn;                             // stride lcn + 1: the steps re-read list heads and must not wait for HBM
 };
 constexpr int kResolveLdsBudget = 156 * 1024;   // dynamic LDS the LDS variant may ask for (160 KB per CU)
-constexpr int kResolveHead = 16;
+constexpr int kResolveHead = 8;
 __host__ __device__ inline size_t resolve_par_bytes(size_t n, size_t nq, size_t lcn = 0)
 {
     n = (n + 3) & ~(size_t)3; nq = (nq + 3) & ~(size_t)3;
-    return (2 * n + nq + n + nq) * 4 + 2 * n + 2 * nq + (HISTO_LENGTH + 2 + 16) * 4 + 8 * nq + (lcn ? nq * (lcn + 1) * 4 : 0);
+    return (2 * n + nq + n + nq) * 4 + 2 * n + 2 * nq + (HISTO_LENGTH + 2 + 16) * 4 + 12 * nq + (lcn ? nq * (lcn + 1) * 4 : 0);
 }
 __device__ __forceinline__ void resolve_par_carve(ResolveParState &S, unsigned char *base, size_t n, size_t nq, int lcn = 0)
 {
@@ -946,6 +947,7 @@ __device__ __forceinline__ void resolve_par_carve(ResolveParState &S, unsigned c
     S.hist = p; p += HISTO_LENGTH + 2; S.vars = p; p += 16;
     S.cur1 = reinterpret_cast<unsigned short *>(p); S.cur2 = S.cur1 + nq; p += nq;
     S.wl[0] = reinterpret_cast<unsigned short *>(p); S.wl[1] = S.wl[0] + nq; p += nq;
+    S.q_cnt = p; p += nq;
     unsigned char *c = reinterpret_cast<unsigned char *>(p);
     S.t_oct = c; c += n; S.taken = c; c += n; S.q_obs = c; c += nq; S.evbin = c;
 }
@@ -981,6 +983,20 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     else resolve_par_carve(S, resolve_lds, (size_t)n_alloc, (size_t)nq_alloc, lcn);
     int *holder = S.owner[0];
     unsigned short *cur1 = S.cur1, *cur2 = S.cur2;
+    // The list heads of this thread's first query are requested before anything else, without waiting for the list
+    // length (a compact list always has its 64 entries allocated), so that ONE memory round trip covers them and the
+    // per-frame state below; heads and lengths then live in LDS: the rounds must never wait for HBM.
+    const bool lc_on = !GS && S.lcn > 0;
+    unsigned long long hv[kResolveHead];
+    int head_c = 0;
+    if (tid < nq) {
+        head_c = cnt[tid];
+        if (lc_on && ccand) {
+            const unsigned long long *l0 = ccand + (size_t)tid * kCompact;
+#pragma unroll
+            for (int e = 0; e < kResolveHead; ++e) hv[e] = l0[e];
+        }
+    }
     for (int i = tid; i < n; i += T) {
         holder[i] = INT_MAX;
         S.taken[i] = (unsigned char)(taken_in ? taken_in[i] != 0 : 0);
@@ -993,22 +1009,22 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
         S.q_obs[i] = (unsigned char)(all_block || q[i].observed != 0);
         S.evbin[i] = 0xff;
         cur1[i] = 0; cur2[i] = 0;
+        S.q_cnt[i] = i == tid ? head_c : cnt[i];
     }
     if (tid < HISTO_LENGTH) S.hist[tid] = 0;
     if (tid < 16) S.vars[tid] = 0;
-    // the head of every sorted list goes to LDS (all loads of a thread are issued together)
-    int head_c = tid < nq ? cnt[tid] : 0;
-    if (!GS && S.lcn > 0) {
+    if (lc_on) {
         for (int i = tid; i < nq; i += T) {
-            const int c = i == tid ? head_c : cnt[i];
+            const int c = S.q_cnt[i];
             if (c <= 0) continue;
-            const unsigned long long *l0 = ccand ? ccand + (size_t)i * kCompact : cand + (size_t)i * stride;
-            unsigned long long v[kResolveHead];
+            if (i != tid || !ccand) {
+                const unsigned long long *l0 = ccand ? ccand + (size_t)i * kCompact : cand + (size_t)i * stride;
 #pragma unroll
-            for (int e = 0; e < kResolveHead; ++e) v[e] = (e < c && e < S.lcn) ? l0[e] : ~0ull;
+                for (int e = 0; e < kResolveHead; ++e) hv[e] = (e < c && e < S.lcn) ? l0[e] : ~0ull;
+            }
 #pragma unroll
             for (int e = 0; e < kResolveHead; ++e)
-                if (e < c && e < S.lcn) S.lc[i * (S.lcn + 1) + e] = ((uint32_t)(v[e] >> 32) << 20) | (uint32_t)(v[e] & 0xfffffu);
+                if (e < c && e < S.lcn) S.lc[i * (S.lcn + 1) + e] = ((uint32_t)(hv[e] >> 32) << 20) | (uint32_t)(hv[e] & 0xfffffu);
         }
     }
     __syncthreads();
@@ -1020,7 +1036,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     unsigned short *wl_next = nullptr;   // set by the event-driven rounds
     int *wl_count = nullptr;
     auto step = [&](int i) -> bool {
-        const int c = i == tid ? head_c : cnt[i];
+        const int c = S.q_cnt[i];
         int newc = -1;
         if (c != 0) {
             const unsigned long long *list = (c > 0 && ccand) ? ccand + (size_t)i * kCompact : cand + (size_t)i * stride;
@@ -1173,8 +1189,13 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     if ((tid & 63) == 0 && acc_local) atomicAdd(&S.vars[1], acc_local);
     __syncthreads();
     if (ori) {
-        int ind1, ind2, ind3;
-        three_maxima(S.hist, ind1, ind2, ind3);
+        if (tid < 64) {   // one wavefront ranks the bins (the pair's 16 wavefronts share one CU's issue slots)
+            int i1, i2, i3;
+            three_maxima(S.hist, i1, i2, i3);
+            if (tid == 0) { S.vars[8] = i1; S.vars[9] = i2; S.vars[10] = i3; }
+        }
+        __syncthreads();
+        const int ind1 = S.vars[8], ind2 = S.vars[9], ind3 = S.vars[10];
         int cull = 0;
         for (int i = tid; i < nq; i += T) {
             const int b = S.evbin[i];
@@ -1183,7 +1204,8 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                 ++cull;
             }
         }
-        if (cull) atomicAdd(&S.vars[2], cull);
+        cull = wave_reduce_add_i(cull);
+        if ((tid & 63) == 0 && cull) atomicAdd(&S.vars[2], cull);
         __syncthreads();
     }
     if (mode == 4) for (int i = tid; i < nq; i += T) out[i] = S.choice[i];   // per query, no slot exclusivity
