@@ -39,12 +39,13 @@ SUM_P = sum(LEVEL_PX)                                   # 1,444,097 px (SURVEY.m
 ALGO_BYTES = {
     "pyramid": LEVEL_PX[0] + (SUM_P - LEVEL_PX[7]) + SUM_P,   # K1: reads P0 + (SumP-P7), writes SumP
     "fast": SUM_P,                                            # K2+K3: reads SumP
-    "blur": 2 * SUM_P,                                        # K6: reads + writes SumP
-    "describe": NFEAT * (749 + 512) + NFEAT * 60,             # K5+K7: gathers + 60 B out per keypoint
+    "blur": 0,                                                # K6 is fused into the descriptor kernel (no blurred plane)
+    "describe": NFEAT * (43 * 43) + NFEAT * 60,               # K5+K6+K7: the 43 x 43 window a keypoint's moments and
+                                                              # blurred 37 x 37 patch depend on + 60 B out per keypoint
     "octree": 0,
 }
-KERNEL_NAME = {"pyramid": "k_pyr_level0+k_pyr_resize(x7)", "fast": "k_fast_cells", "blur": "k_blur",
-               "describe": "k_orient_describe", "octree": "k_octree"}
+KERNEL_NAME = {"pyramid": "k_pyr_base+k_pyr_rows(x6)", "fast": "k_fast_cells", "blur": "(fused into k_describe_fused)",
+               "describe": "k_describe_fused", "octree": "k_octree"}
 FRAME_BYTES_MODEL = 8971771                             # BASELINE.md section 3, whole path
 HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, KITTI_BF = 718.856, 718.856, 607.1928, 185.2157, 386.1448   # KITTI00-02.yaml
@@ -450,10 +451,10 @@ def main():
         fps_k = B * world * args.steps / dt_k                   # exactly K steps
         # dominant single kernel: largest HIP-event time among the one-launch stages (the pyramid stage is 8
         # dependent launches, the matching 4 small ones)
-        kern = max(("fast", "blur", "describe"), key=lambda k: stage[k])
+        kern = max(("fast", "describe"), key=lambda k: stage[k])
         if stage["fast"] >= 0.8 * stage[kern]:
-            kern = "fast"     # rocprofv3 --stats: k_fast_cells has the largest total time of any single kernel; with two
-                              # pipelines interleaved the HBM-bound blur is stretched more than the VALU-bound FAST
+            kern = "fast"     # rocprofv3 --stats: k_fast_cells has the largest total time of any single kernel; with several
+                              # pipelines interleaved the other kernels are stretched more than the VALU-bound FAST
         algo = ALGO_BYTES[kern] * Bh                # frames per launch of one handle
         achieved = algo / (stage[kern] * 1e-6) / 1e9
         traffic, valu = None, None

@@ -21,24 +21,30 @@ def hbm(k):
     return v.get("hbm_read_bytes_corrected", 0) + v.get("hbm_write_bytes", 0)
 
 
-kf, kb, kd, ko = find("k_fast_cells"), find("k_blur"), find("k_orient_describe"), find("k_octree")
+kf, kd, ko = find("k_fast_cells"), find("k_describe_fused"), find("k_octree")
+npyr_rows = int(sys.argv[3]) if len(sys.argv) > 3 else 6   # k_pyr_rows launches per frame batch (levels 2 .. 7)
 out = {
     "_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 4 --min-time 0 --handles 1 "
                "(%d frames 1241x376 per launch); bytes are per frame; FETCH_SIZE x2 (gfx950, wide coalesced reads: an upper "
                "bound for gather-shaped kernels)" % frames,
     "fast": {"kernel": kf, "hbm_bytes_per_frame": round(hbm(kf) / frames)},
-    "blur": {"kernel": kb, "hbm_bytes_per_frame": round(hbm(kb) / frames)},
+    "blur": {"kernel": "(fused into k_describe_fused: no blurred plane is written)", "hbm_bytes_per_frame": 0},
     "describe": {"kernel": kd, "hbm_bytes_per_frame": round(hbm(kd) / frames)},
-    "pyramid": {"kernel": "k_pyr_level0 + 7 x k_pyr_resize",
-                "hbm_bytes_per_frame": round((hbm(find("k_pyr_level0")) + 7 * hbm(find("k_pyr_resize"))) / frames)},
+    "pyramid": {"kernel": "k_pyr_base + %d x k_pyr_rows" % npyr_rows,
+                "hbm_bytes_per_frame": round((hbm(find("k_pyr_base")) + npyr_rows * hbm(find("k_pyr_rows"))) / frames)},
     "octree": {"kernel": ko, "hbm_bytes_per_frame": round(hbm(ko) / frames)},
 }
 # VALU issue load of every stage ("report VALU utilisation alongside"): one VALU instruction occupies its
 # SIMD for 4 cycles (wave64 on a 16-lane SIMD); 256 CUs x 4 SIMDs, 2.4 GHz
-for stage, key in (("fast", kf), ("blur", kb), ("describe", kd)):
+for stage, key in (("fast", kf), ("describe", kd), ("octree", ko)):
     v = d[key]
     if "SQ_INSTS_VALU" in v:
         out[stage]["valu_insts_per_frame"] = round(v["SQ_INSTS_VALU"] / frames)
         out[stage]["valu_issue_us_per_frame"] = round(v["SQ_INSTS_VALU"] / frames * 4 / 1024 / 2.4e3, 4)
+v = [d[find("k_pyr_base")], d[find("k_pyr_rows")]]
+if all("SQ_INSTS_VALU" in x for x in v):
+    n = v[0]["SQ_INSTS_VALU"] + npyr_rows * v[1]["SQ_INSTS_VALU"]
+    out["pyramid"]["valu_insts_per_frame"] = round(n / frames)
+    out["pyramid"]["valu_issue_us_per_frame"] = round(n / frames * 4 / 1024 / 2.4e3, 4)
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

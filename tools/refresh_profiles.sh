@@ -1,15 +1,15 @@
 #!/bin/bash
 # Regenerates the measurement artefacts kept under profiles/ (run on the GPU box through gpurun):
-#   kernel-trace stats for the default two pipelines and for one pipeline alone, PMC passes (1 pipeline),
+#   kernel-trace stats for the default three pipelines and for one pipeline alone, PMC passes (1 pipeline),
 #   the plain bench line, host-path rates.  Outputs land in gpurun_out/refresh/.
 set -e
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof_handles2.json 2> $OUT/stats2.err
-cp $(find $OUT/stats2 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_handles2.csv
-echo "stats (2 pipelines) done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof_handles3.json 2> $OUT/stats2.err
+cp $(find $OUT/stats2 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_handles3.csv
+echo "stats (3 pipelines) done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --handles 1 --frames-per-gpu 64 > $OUT/bench_under_rocprof_handles1.json 2> $OUT/stats1.err
 cp $(find $OUT/stats1 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_handles1.csv
 echo "stats (1 pipeline) done"
