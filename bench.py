@@ -433,6 +433,16 @@ def main():
     assert int(o["st"].abs().sum().item()) == 0 and n_host.min() > 0, "extraction failed"
     assert nm_host.min() > 100, "SearchByProjection found too few matches: the synthetic pairs are broken"
 
+    # pipeline 0 once more, ALONE on the GPU (the other pipelines idle): the stand-alone launch times of its kernels, which
+    # is what rocprofv3 shows for a single-pipeline run; reported beside the contended times of the timed region above
+    torch.cuda.synchronize(dev)
+    exts[0].set_profiling(True)
+    for _ in range(40):
+        extract_all(obuf[0], which=0)
+    torch.cuda.synchronize(dev)
+    stage_alone = exts[0].stage_times_us()
+    exts[0].set_profiling(False)
+
     if os.environ.get("ORBHIP_DEV_STATS"):
         import ctypes as C
         from orb_slam2_comment_amd.capi import lib
@@ -500,6 +510,15 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "valu_issue": valu,
                          "algorithmic_bytes_per_launch": algo,
                          "avg_launch_us": round(stage[kern], 2),
+                         "alone": {"what": "the same launch (%d frames) with no other pipeline on the GPU" % Bh,
+                                   "avg_launch_us": round(stage_alone[kern], 2),
+                                   "achieved": round(algo / (stage_alone[kern] * 1e-6) / 1e9, 2),
+                                   "frac": round(algo / (stage_alone[kern] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+                                   "stage_us": {k: round(v, 2) for k, v in stage_alone.items()}},
+                         "other_stages": {k: {"kernel": KERNEL_NAME[k], "algorithmic_bytes_per_launch": ALGO_BYTES[k] * Bh,
+                                              "frac": round(ALGO_BYTES[k] * Bh / (stage[k] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+                                              "frac_alone": round(ALGO_BYTES[k] * Bh / (stage_alone[k] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)}
+                                          for k in ("pyramid", "describe") if stage[k] > 0 and stage_alone[k] > 0},
                          "stage_us": {k: round(v, 2) for k, v in stage.items()},
                          "whole_path_GBps_model": round(FRAME_BYTES_MODEL * fps / world / 1e9, 2)},
         }

@@ -439,10 +439,11 @@ __device__ __forceinline__ void pyr_resize_rows(const PyrLevelTab &T, int unit, 
 // level 0 + level 1 of a frame in one launch: workgroups [0, nb0) copy, the rest resize from the input image
 __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ images, int stride, size_t frame_stride,
                                                   uint8_t *__restrict__ pyr, uint32_t frame_bytes, PyrLevelTab T0,
-                                                  PyrLevelTab T1, int nb0)
+                                                  PyrLevelTab T1, int nb0, int *__restrict__ status)
 {
     int bx, fr;
     xcd_remap(bx, fr);
+    if (bx == 0 && threadIdx.x == 0) status[fr] = 0;   // the frame's status word starts every extraction at ORBHIP_OK
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint8_t *src = images + (size_t)fr * frame_stride;
     uint8_t *frame = pyr + (size_t)fr * frame_bytes;
@@ -2024,7 +2025,9 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     const bool prof = e->profiling;
     hipEvent_t *ev = prof ? &e->ev[(size_t)(e->prof_calls % orbhip_extractor::kProfRing) * orbhip_extractor::kProfEv] : nullptr;
     int *status = d_status ? d_status : e->d_status + frame0;
-    hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
+    static const bool dev_old_pyr = getenv("ORBHIP_PYR_GENERAL") != nullptr;
+    if (dev_old_pyr || !(e->stage_mask & 1))   // k_pyr_base clears the status words itself
+        hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
     if (prof) (void)hipEventRecord(ev[0], s);
     const int sm = e->stage_mask;   // development switch (tools/coexec.py): run a subset of the stages on buffers a full run left
     if (sm & 1) {
@@ -2037,7 +2040,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
             if (!l1_rows) memset(&T1, 0, sizeof(T1));
             const int nb0 = (e->ptab[0].units + 3) / 4, nb1 = (T1.units + 3) / 4;
             hipLaunchKernelGGL(k_pyr_base, dim3(nb0 + nb1, batch), dim3(256), 0, s, d_images, stride, frame_stride, b_pyr,
-                               G.frame_bytes, e->ptab[0], T1, nb0);
+                               G.frame_bytes, e->ptab[0], T1, nb0, status);
             if (l1_rows) first = 2;
         } else {
             const LevelGeom &L = G.lv[0];

@@ -100,12 +100,12 @@ __global__ void k_grid_order(DevFrame F, uint32_t *__restrict__ ord, Batch B)
 // cell and never candidates.
 constexpr int kGridCells = GRID_COLS * GRID_ROWS;
 struct GridRec { float x, y; int octave; uint32_t key; };   // key = cell << 20 | index
-__global__ __launch_bounds__(256) void k_grid_build(DevFrame F, int *__restrict__ cell_start, GridRec *__restrict__ rec,
-                                                    uint4 *__restrict__ rdesc, float *__restrict__ rur, Batch B)
+__device__ __forceinline__ void grid_build_body(DevFrame F, int *__restrict__ cell_start, GridRec *__restrict__ rec,
+                                                uint4 *__restrict__ rdesc, float *__restrict__ rur, const Batch &B, const int pair)
 {
     __shared__ int s_cnt[kGridCells];
     __shared__ int s_scan[8];
-    const int tid = threadIdx.x, pair = blockIdx.x;
+    const int tid = threadIdx.x;
     batch_frame(F, B, pair);
     const size_t rbase = (size_t)pair * (B.cap > 0 ? B.cap : F.n);
     cell_start += (size_t)pair * (kGridCells + 1);
@@ -151,6 +151,11 @@ __global__ __launch_bounds__(256) void k_grid_build(DevFrame F, int *__restrict_
             rur[pos] = F.u_right ? F.u_right[j] : -1.0f;
         }
     }
+}
+__global__ __launch_bounds__(256) void k_grid_build(DevFrame F, int *__restrict__ cell_start, GridRec *__restrict__ rec,
+                                                    uint4 *__restrict__ rdesc, float *__restrict__ rur, Batch B)
+{
+    grid_build_body(F, cell_start, rec, rdesc, rur, B, (int)blockIdx.x);
 }
 
 // One wavefront per query.  The cells of the query's window (Frame.cc:332-346) are dealt to the lanes; the records of
@@ -1464,9 +1469,9 @@ struct ProjBatch {
 };
 
 // src/ORBmatcher.cc:1339-1390
-__global__ __launch_bounds__(256) void k_project_last_frame(ProjBatch B, orbhip_camera cam, float th, int mono)
+__device__ __forceinline__ void project_last_frame_body(const ProjBatch &B, const orbhip_camera &cam, const float th, const int mono,
+                                                        const int pair, const int i)
 {
-    const int pair = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     const size_t fl = (size_t)(B.l0 + pair * B.ls);
     const int n = B.n_dev ? min(B.n_dev[fl], B.cap) : B.n;
     if (i == 0 && B.nq) B.nq[pair] = n;
@@ -1510,6 +1515,21 @@ __global__ __launch_bounds__(256) void k_project_last_frame(ProjBatch B, orbhip_
     }
     *dst = Q;
 }
+__global__ __launch_bounds__(256) void k_project_last_frame(ProjBatch B, orbhip_camera cam, float th, int mono)
+{
+    project_last_frame_body(B, cam, th, mono, (int)blockIdx.y, (int)(blockIdx.x * 256 + threadIdx.x));
+}
+// TrackWithMotionModel's matching step: the projection prologue and the CSR grid of the current frames do not depend on
+// each other, so they share one launch: per pair one workgroup builds the grid, `npb` workgroups project
+__global__ __launch_bounds__(256) void k_grid_build_project(DevFrame F, int *__restrict__ cell_start, GridRec *__restrict__ rec,
+                                                            uint4 *__restrict__ rdesc, float *__restrict__ rur, Batch B,
+                                                            ProjBatch P, orbhip_camera cam, float th, int mono, int npb)
+{
+    const int pair = (int)blockIdx.x / (npb + 1), role = (int)blockIdx.x - pair * (npb + 1);
+    if (role == 0) grid_build_body(F, cell_start, rec, rdesc, rur, B, pair);
+    else project_last_frame_body(P, cam, th, mono, pair, (role - 1) * 256 + (int)threadIdx.x);
+}
+struct ProjLaunch { ProjBatch P; orbhip_camera cam; float th; int mono; };
 
 struct FrustumBatch {
     const float *Tcw;                       // [frames][12]
@@ -2023,7 +2043,7 @@ static int launch_resolve_par(orbhip_matcher *m, int pairs, int mode, const DevF
 // CSR grid of the train frames + the cell-window search: candidates of every query
 static int launch_window_search(orbhip_matcher *m, int pairs, const DevFrame &D, int n_train_cap, const orbhip_query *d_q,
                                 const uint8_t *d_qdesc, int nq, unsigned long long *d_cand, int *d_cnt, int stride, int use_ur,
-                                const Batch &B, unsigned long long **d_ccand_out)
+                                const Batch &B, unsigned long long **d_ccand_out, const ProjLaunch *proj = nullptr)
 {
     void *p;
     int rc;
@@ -2038,7 +2058,13 @@ static int launch_window_search(orbhip_matcher *m, int pairs, const DevFrame &D,
     float *d_rur = (float *)((uint8_t *)d_rdesc + al256(nrec * 32));
     if ((rc = scratch(m, S_CCAND, (size_t)pairs * nq * kCompact * sizeof(unsigned long long), &p))) return rc;
     unsigned long long *d_ccand = (unsigned long long *)p;
-    hipLaunchKernelGGL(k_grid_build, dim3(pairs), dim3(256), 0, m->stream, D, d_start, d_rec, d_rdesc, d_rur, B);
+    if (proj) {   // the projection prologue rides in the grid launch
+        const int npb = (proj->P.cap + 255) / 256;
+        hipLaunchKernelGGL(k_grid_build_project, dim3(pairs * (npb + 1)), dim3(256), 0, m->stream, D, d_start, d_rec, d_rdesc, d_rur, B,
+                           proj->P, proj->cam, proj->th, proj->mono, npb);
+    } else {
+        hipLaunchKernelGGL(k_grid_build, dim3(pairs), dim3(256), 0, m->stream, D, d_start, d_rec, d_rdesc, d_rur, B);
+    }
     hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4, pairs), dim3(256), 0, m->stream, D, d_start, d_rec, d_rdesc, d_rur, d_q,
                        d_qdesc, nq, d_cand, d_ccand, d_cnt, stride, use_ur, B);
     *d_ccand_out = d_ccand;
@@ -2730,7 +2756,8 @@ int orbhip_search_by_projection_points(orbhip_matcher *m, const orbhip_frame_vie
 static int search_device(orbhip_matcher *m, int mode, int pairs, const void *d_kps, const void *d_desc, const void *d_n,
                          int cap, const void *d_u_right, const void *d_taken, float min_x, float min_y, float grid_inv_w,
                          float grid_inv_h, const void *d_q, const void *d_qdesc, const void *d_nq, int qcap, float nnratio,
-                         int check_ori, void *d_assign, void *d_nmatches, int t0 = 0, int ts = 1, int qd0 = 0, int qds = 1)
+                         int check_ori, void *d_assign, void *d_nmatches, int t0 = 0, int ts = 1, int qd0 = 0, int qds = 1,
+                         const ProjLaunch *proj = nullptr)
 {
     if (!m || pairs <= 0 || !d_kps || !d_desc || !d_n || !d_q || !d_qdesc || !d_nq || !d_assign || !d_nmatches || cap <= 0 || qcap <= 0)
         return ORBHIP_E_ARG;
@@ -2749,7 +2776,7 @@ static int search_device(orbhip_matcher *m, int mode, int pairs, const void *d_k
     const Batch B = {(const int *)d_n, (const int *)d_nq, cap, qcap, t0, ts, qd0, qds};
     unsigned long long *d_ccand;
     if ((rc = launch_window_search(m, pairs, D, cap, (const orbhip_query *)d_q, (const uint8_t *)d_qdesc, qcap, d_cand, d_cnt, stride, 1,
-                                   B, &d_ccand)))
+                                   B, &d_ccand, proj)))
         return rc;
     if ((rc = launch_resolve_par(m, pairs, mode, D, (const orbhip_query *)d_q, qcap, cap, d_cand, d_ccand, d_cnt, stride,
                                  (const uint8_t *)d_taken, nnratio, check_ori, (int *)d_assign, (int *)d_nmatches, B, TH_HIGH, 0)))
@@ -2893,13 +2920,16 @@ int orbhip_track_last_frame_device(orbhip_matcher *m, int pairs, const orbhip_ca
     orbhip_query *d_q = (orbhip_query *)p;
     if ((rc = scratch(m, S_TAKEN, (size_t)pairs * sizeof(int), &p))) return rc;   // per-pair query counts
     int *d_nq = (int *)p;
-    if ((rc = orbhip_project_last_frame_device(m, pairs, cam, d_Tcw, d_Tlw, d_kps, d_n, cap, last_first, last_step, d_world,
-                                               d_flags, th, mono, d_q, d_nq)))
-        return rc;
+    if (!d_Tcw || !d_Tlw || !d_kps || !d_n || !d_world || !d_flags || cam->n_levels < 1 || cam->n_levels > ORBHIP_MAX_LEVELS)
+        return ORBHIP_E_ARG;
+    ProjLaunch proj;
+    proj.P = {(const float *)d_Tcw, (const float *)d_Tlw, (const orbhip_keypoint *)d_kps, (const int *)d_n,
+              (const float *)d_world, (const uint8_t *)d_flags, d_q, d_nq, 0, cap, last_first, last_step};
+    proj.cam = *cam; proj.th = th; proj.mono = mono;
     // Frame::ComputeImageBounds / mfGridElement{Width,Height}Inv (src/Frame.cc:99-100) from the camera's bounds
     const float inv_w = (float)GRID_COLS / (cam->max_x - cam->min_x), inv_h = (float)GRID_ROWS / (cam->max_y - cam->min_y);
     return search_device(m, 0, pairs, d_kps, d_desc, d_n, cap, d_u_right, d_taken, cam->min_x, cam->min_y, inv_w, inv_h, d_q,
-                         d_desc, d_nq, cap, 0.f, check_ori, d_assign, d_nmatches, cur_first, cur_step, last_first, last_step);
+                         d_desc, d_nq, cap, 0.f, check_ori, d_assign, d_nmatches, cur_first, cur_step, last_first, last_step, &proj);
 }
 
 int orbhip_frustum_queries_device(orbhip_matcher *m, int frames, const orbhip_camera *cam, const void *d_Tcw, int pcap,
