@@ -786,21 +786,24 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 // list order (new children reversed in front, survivors behind) and relabels keys.
 // ---------------------------------------------------------------------------
 constexpr int kOctU = 4;            // independent keys per thread in the key loops
-constexpr int kOctKeysLds = 6144;   // keys held in LDS (36 KB); larger levels use the HBM workspace
+// keys held in LDS (36 KB for the 512-node variant, 12 KB for the 2048-node one, whose node tables are 4x larger); levels
+// with more candidates use the HBM workspace
+template <int MAXN> constexpr int oct_keys_lds() { return MAXN <= 512 ? 6144 : 2048; }
 
 template <int MAXN>
 struct OctShared {
     short x0[2][MAXN], x1[2][MAXN], y0[2][MAXN], y1[2][MAXN];
     int cnt[2][MAXN];
-    int ccnt[MAXN * 4];
-    int nmap[MAXN];            // survivors: new index; split nodes: 0x40000000 | creation base
+    int ccnt[2][MAXN * 4];     // child counters of a pass (then: new index of every created child); double-buffered so that
+                               // the next pass's buffer is cleared while the keys are still being relabelled from this one
+    int nmap[MAXN];            // survivors: new index; split nodes: 0x40000000
     unsigned short ord[MAXN];  // processing order -> node
     unsigned short rnk[MAXN];  // node -> processing rank (0xffff: not expandable)
     int cincl[MAXN];           // inclusive scan of child counts in processing order
     int scan[16];
     int vars[8];
-    uint32_t lkeys[kOctKeysLds];        // candidate keys (x | y<<12 | score<<24) when they fit
-    unsigned short lnode[kOctKeysLds];  // owning node of each key
+    uint32_t lkeys[oct_keys_lds<MAXN>()];        // candidate keys (x | y<<12 | score<<24) when they fit
+    unsigned short lnode[oct_keys_lds<MAXN>()];  // owning node of each key
 };
 
 template <int MAXN, bool INLDS, int T>
@@ -825,12 +828,12 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
             const int k = k0 + u * T + tid;
             v[u] = 0;
             if (k < K) {
-                int lo = 0, hi = L.ncells - 1;      // last cell c with S.ccnt[c] <= k
+                int lo = 0, hi = L.ncells - 1;      // last cell c with S.ccnt[0][c] <= k
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
-                    if (S.ccnt[mid] <= k) lo = mid; else hi = mid - 1;
+                    if (S.ccnt[0][mid] <= k) lo = mid; else hi = mid - 1;
                 }
-                v[u] = ckp_in[(size_t)lo * G.slot_cap + (k - S.ccnt[lo])];
+                v[u] = ckp_in[(size_t)lo * G.slot_cap + (k - S.ccnt[0][lo])];
             }
         }
 #pragma unroll
@@ -849,7 +852,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         S.x1[0][i] = (short)(int)__fmul_rn(L.hX, (float)(i + 1));
         S.y0[0][i] = 0;
         S.y1[0][i] = (short)height;
-        S.ccnt[i] = 0;
+        S.ccnt[0][i] = 0;
     }
     __syncthreads();
     for (int k0 = 0; k0 < K; k0 += T * kOctU) {
@@ -862,7 +865,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
             if (k < K) {
                 const int bin = min((int)__fdiv_rn((float)(kv[u] & 0xfffu), L.hX), nIni - 1);
                 knode(k) = (unsigned short)bin;
-                atomicAdd(&S.ccnt[bin], 1);
+                atomicAdd(&S.ccnt[0][bin], 1);
             }
         }
     }
@@ -873,7 +876,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         int carry = 0;
         for (int i0 = 0; i0 < nIni; i0 += T) {
             int i = i0 + tid;
-            int c = i < nIni ? S.ccnt[i] : 0;
+            int c = i < nIni ? S.ccnt[0][i] : 0;
             int pos = carry + block_excl_scan<T>(c > 0, S.scan, &tot);
             if (i < nIni) {
                 S.nmap[i] = pos;
@@ -901,12 +904,20 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
     int cur = 1;
     int phase = 1;
     bool finish = (K == 0);
+    int cb = 0;     // child-counter buffer of this pass
+    // the first pass's counters (the gather and the root binning used buffer 0 for other things)
+    for (int i = tid; i < n * 4; i += T) S.ccnt[0][i] = 0;
+    __syncthreads();
 
+    // A pass = [all wavefronts] count the children of every expandable node over the keys -> barrier ->
+    // [ONE wavefront] the node-table work: which nodes split, the new table in list order, where every created child and
+    // every survivor lands -> barrier -> [all wavefronts] relabel the keys.  The node table has a few hundred entries
+    // at most; doing its scans with the whole workgroup cost 15 barriers and 8 wavefronts' worth of instructions per
+    // pass on a CU whose issue slots the workgroup shares with another level's, so one wavefront does it with
+    // wave-level scans (a lane owns `per` consecutive nodes) while the others wait at the barrier.
     while (!finish) {
         const int prevSize = n;
-        // A: zero child counters
-        for (int i = tid; i < n * 4; i += T) S.ccnt[i] = 0;
-        __syncthreads();
+        int *CC = S.ccnt[cb];
         // B: count children of expandable nodes (DivideNode :481-526)
         for (int k0 = 0; k0 < K; k0 += T * kOctU) {
             // kOctU independent keys per thread: the LDS round trips of the chains overlap
@@ -932,118 +943,133 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
                 if (k < K && cn[u] > 1) {
                     const int x = kv[u] & 0xfff, y = (kv[u] >> 12) & 0xfff;
                     const int mx = bx0[u] + ((bx1[u] - bx0[u] + 1) >> 1), my = by0[u] + ((by1[u] - by0[u] + 1) >> 1);
-                    atomicAdd(&S.ccnt[4 * nd[u] + (x < mx ? 0 : 1) + (y < my ? 0 : 2)], 1);
+                    atomicAdd(&CC[4 * nd[u] + (x < mx ? 0 : 1) + (y < my ? 0 : 2)], 1);
                 }
             }
         }
         __syncthreads();
-        // C: processing rank of every expandable node
-        int m = 0;
-        if (phase == 1) {
-            int carry = 0;
-            for (int i0 = 0; i0 < n; i0 += T) {
-                int i = i0 + tid;
-                int e = (i < n && S.cnt[cur][i] > 1) ? 1 : 0;
-                int r = carry + block_excl_scan<T>(e, S.scan, &tot);
-                if (i < n) S.rnk[i] = e ? (unsigned short)r : (unsigned short)0xffff;
-                if (e) S.ord[r] = (unsigned short)i;
-                carry += tot;
-            }
-            m = carry;
-        } else {
-            // (size desc, list position asc): the reference sorts (size, node address) ascending
-            // and walks from the back (:684-685); "newer node first" stands in for the address.
-            int carry = 0;
-            for (int i0 = 0; i0 < n; i0 += T) {
-                int i = i0 + tid;
-                int e = (i < n && S.cnt[cur][i] > 1) ? 1 : 0;
-                int r = 0;
-                if (e) {
-                    int ci = S.cnt[cur][i];
+        if (phase == 2) {
+            // processing order of the careful phase: (size desc, list position asc) -- the reference sorts (size, node
+            // address) ascending and walks from the back (:684-685); "newer node first" stands in for the address.
+            // O(n^2) comparisons, spread over the whole workgroup (once per level).
+            for (int i = tid; i < n; i += T) {
+                const int ci = S.cnt[cur][i];
+                if (ci > 1) {
+                    int r = 0;
 #pragma unroll 8
                     for (int j = 0; j < n; ++j) {
-                        int cj = S.cnt[cur][j];
+                        const int cj = S.cnt[cur][j];
                         r += (cj > 1) && (cj > ci || (cj == ci && j < i));
                     }
                     S.rnk[i] = (unsigned short)r;
                     S.ord[r] = (unsigned short)i;
-                } else if (i < n) S.rnk[i] = 0xffff;
-                int dummy = block_excl_scan<T>(e, S.scan, &tot);
-                (void)dummy;
-                carry += tot;
-            }
-            m = carry;
-        }
-        __syncthreads();
-        // D: inclusive scan of child counts in processing order; find the break index J
-        int Jfound = 0x7fffffff;
-        {
-            int carry = 0;
-            for (int j0 = 0; j0 < m; j0 += T) {
-                int j = j0 + tid;
-                int nc = 0;
-                if (j < m) {
-                    int nd = S.ord[j];
-                    nc = (S.ccnt[4 * nd] > 0) + (S.ccnt[4 * nd + 1] > 0) + (S.ccnt[4 * nd + 2] > 0) + (S.ccnt[4 * nd + 3] > 0);
+                } else {
+                    S.rnk[i] = 0xffff;
                 }
-                int ex = carry + block_excl_scan<T>(nc, S.scan, &tot);
-                if (j < m) {
-                    S.cincl[j] = ex + nc;
-                    if (phase == 2 && n + ex + nc - (j + 1) >= N) Jfound = min(Jfound, j);
-                }
-                carry += tot;
             }
+            __syncthreads();
         }
-        if (tid == 0) S.vars[0] = 0x7fffffff;
-        __syncthreads();
-        if (Jfound != 0x7fffffff) atomicMin(&S.vars[0], Jfound);
-        __syncthreads();
-        int J = S.vars[0];
-        if (J == 0x7fffffff) J = m - 1;
-        const int Gc = (m > 0) ? S.cincl[J] : 0;  // children created this pass
-        // E: build the new table: children reversed in front, survivors behind in order
         const int nxt = cur ^ 1;
-        int nToExpand = 0;
-        {
-            int carry = 0;
-            for (int i0 = 0; i0 < n; i0 += T) {
-                int i = i0 + tid;
-                int split = 0;
-                if (i < n) { int r = S.rnk[i]; split = (r != 0xffff && r <= J); }
-                int surv = (i < n && !split) ? 1 : 0;
-                int spos = carry + block_excl_scan<T>(surv, S.scan, &tot);
-                if (i < n) {
-                    if (surv) {
-                        int ni = Gc + spos;
+        if (tid < 64) {
+            const int lane = tid;
+            const int per = (n + 63) >> 6;                 // consecutive nodes (or ranks) per lane
+            const int i_lo = lane * per, i_hi = min(i_lo + per, n);
+            // C: processing rank of every expandable node (phase 1: list order)
+            int m;
+            {
+                int e_cnt = 0;
+                for (int i = i_lo; i < i_hi; ++i) e_cnt += S.cnt[cur][i] > 1;
+                int incl = e_cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+                m = __shfl(incl, 63, 64);
+                if (phase == 1) {
+                    int r = incl - e_cnt;
+                    for (int i = i_lo; i < i_hi; ++i) {
+                        if (S.cnt[cur][i] > 1) { S.rnk[i] = (unsigned short)r; S.ord[r] = (unsigned short)i; ++r; }
+                        else S.rnk[i] = 0xffff;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // D: inclusive scan of the child counts in processing order; the break index J of the careful phase
+            const int perm = (m + 63) >> 6;
+            const int j_lo = lane * perm, j_hi = min(j_lo + perm, m);
+            int J, Gc;
+            {
+                int sum = 0;
+                for (int j = j_lo; j < j_hi; ++j) {
+                    const int nd = S.ord[j];
+                    sum += (CC[4 * nd] > 0) + (CC[4 * nd + 1] > 0) + (CC[4 * nd + 2] > 0) + (CC[4 * nd + 3] > 0);
+                }
+                int incl = sum;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+                int run = incl - sum, jf = 0x7fffffff;
+                for (int j = j_lo; j < j_hi; ++j) {
+                    const int nd = S.ord[j];
+                    run += (CC[4 * nd] > 0) + (CC[4 * nd + 1] > 0) + (CC[4 * nd + 2] > 0) + (CC[4 * nd + 3] > 0);
+                    S.cincl[j] = run;
+                    if (phase == 2 && jf == 0x7fffffff && n + run - (j + 1) >= N) jf = j;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) jf = min(jf, __shfl_xor(jf, off, 64));
+                J = jf == 0x7fffffff ? m - 1 : jf;
+            }
+            __builtin_amdgcn_wave_barrier();
+            Gc = m > 0 ? S.cincl[J] : 0;   // children created this pass
+            // E: the new table: children reversed in front, survivors behind in order
+            int nToExpand = 0;
+            {
+                int surv_cnt = 0;
+                for (int i = i_lo; i < i_hi; ++i) { const int r = S.rnk[i]; surv_cnt += !(r != 0xffff && r <= J); }
+                int incl = surv_cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+                int spos = incl - surv_cnt;
+                for (int i = i_lo; i < i_hi; ++i) {
+                    const int r = S.rnk[i];
+                    const bool split = r != 0xffff && r <= J;
+                    if (!split) {
+                        const int ni = Gc + spos++;
                         S.nmap[i] = ni;
                         S.x0[nxt][ni] = S.x0[cur][i]; S.x1[nxt][ni] = S.x1[cur][i];
                         S.y0[nxt][ni] = S.y0[cur][i]; S.y1[nxt][ni] = S.y1[cur][i];
                         S.cnt[nxt][ni] = S.cnt[cur][i];
                     } else {
-                        int r = S.rnk[i];
-                        int cbase = (r > 0) ? S.cincl[r - 1] : 0;
-                        S.nmap[i] = 0x40000000 | cbase;
-                        int px0 = S.x0[cur][i], px1 = S.x1[cur][i], py0 = S.y0[cur][i], py1 = S.y1[cur][i];
-                        int mx = px0 + ((px1 - px0 + 1) >> 1), my = py0 + ((py1 - py0 + 1) >> 1);
-                        int g = cbase;
+                        S.nmap[i] = 0x40000000;
+                        const int px0 = S.x0[cur][i], px1 = S.x1[cur][i], py0 = S.y0[cur][i], py1 = S.y1[cur][i];
+                        const int mx = px0 + ((px1 - px0 + 1) >> 1), my = py0 + ((py1 - py0 + 1) >> 1);
+                        int g = r > 0 ? S.cincl[r - 1] : 0;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            int c = S.ccnt[4 * i + q];
+                            const int c = CC[4 * i + q];
                             if (c > 0) {
-                                int ni = Gc - 1 - g;
+                                const int ni = Gc - 1 - g;
                                 S.x0[nxt][ni] = (short)((q & 1) ? mx : px0);
                                 S.x1[nxt][ni] = (short)((q & 1) ? px1 : mx);
                                 S.y0[nxt][ni] = (short)((q & 2) ? my : py0);
                                 S.y1[nxt][ni] = (short)((q & 2) ? py1 : my);
                                 S.cnt[nxt][ni] = c;
+                                CC[4 * i + q] = ni;          // the keys of this quadrant move to node ni
                                 nToExpand += (c > 1);
                                 ++g;
                             }
                         }
                     }
                 }
-                carry += tot;
             }
+            // G: bookkeeping (:669-673, :734)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nToExpand += __shfl_xor(nToExpand, off, 64);
+            const int n_new = Gc + (n - (m > 0 ? J + 1 : 0));
+            int fin = 0, ph = phase;
+            if (n_new >= N || n_new == prevSize) fin = 1;
+            else if (phase == 1 && n_new + nToExpand * 3 > N) ph = 2;
+            if (lane == 0) { S.vars[0] = n_new; S.vars[1] = fin; S.vars[2] = ph; }
+            // the next pass's counters
+            int *CN = S.ccnt[cb ^ 1];
+            for (int i = lane; i < n_new * 4; i += 64) CN[i] = 0;
         }
         __syncthreads();
         // F: relabel keys
@@ -1058,12 +1084,11 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
             }
 #pragma unroll
             for (int u = 0; u < kOctU; ++u) mp[u] = S.nmap[nd[u]];
-            int bx0[kOctU], bx1[kOctU], by0[kOctU], by1[kOctU], c0[kOctU], c1[kOctU], c2[kOctU];
+            int bx0[kOctU], bx1[kOctU], by0[kOctU], by1[kOctU];
 #pragma unroll
             for (int u = 0; u < kOctU; ++u) {
                 bx0[u] = S.x0[cur][nd[u]]; bx1[u] = S.x1[cur][nd[u]];
                 by0[u] = S.y0[cur][nd[u]]; by1[u] = S.y1[cur][nd[u]];
-                c0[u] = S.ccnt[4 * nd[u]]; c1[u] = S.ccnt[4 * nd[u] + 1]; c2[u] = S.ccnt[4 * nd[u] + 2];
             }
 #pragma unroll
             for (int u = 0; u < kOctU; ++u) {
@@ -1072,30 +1097,24 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
                 if (mp[u] & 0x40000000) {
                     const int x = kv[u] & 0xfff, y = (kv[u] >> 12) & 0xfff;
                     const int mx = bx0[u] + ((bx1[u] - bx0[u] + 1) >> 1), my = by0[u] + ((by1[u] - by0[u] + 1) >> 1);
-                    const int q = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
-                    int g = mp[u] & 0x3fffffff;
-                    g += (q > 0 && c0[u] > 0) + (q > 1 && c1[u] > 0) + (q > 2 && c2[u] > 0);
-                    knode(k) = (unsigned short)(Gc - 1 - g);
+                    knode(k) = (unsigned short)CC[4 * nd[u] + (x < mx ? 0 : 1) + (y < my ? 0 : 2)];
                 } else {
                     knode(k) = (unsigned short)mp[u];
                 }
             }
         }
-        // G: bookkeeping (:669-673, :734)
-        if (tid == 0) S.vars[1] = 0;
-        __syncthreads();
-        if (nToExpand) atomicAdd(&S.vars[1], nToExpand);
-        __syncthreads();
-        const int nToExpandAll = S.vars[1];
-        n = Gc + (n - ((m > 0) ? (J + 1) : 0));
+        n = S.vars[0];
+        finish = S.vars[1] != 0;
+        phase = S.vars[2];
         cur = nxt;
-        if (n >= N || n == prevSize) finish = true;
-        else if (phase == 1 && n + nToExpandAll * 3 > N) phase = 2;
-        __syncthreads();
+        cb ^= 1;
+        // no barrier here: the next pass's counting reads only what the node-table wavefront published before the barrier
+        // above and the node labels this thread wrote itself; S.vars is rewritten after the next barrier
     }
+    __syncthreads();
 
     // ---- retain the best key of every node, first index wins ties (:742-760) ----
-    unsigned int *best = reinterpret_cast<unsigned int *>(S.ccnt);
+    unsigned int *best = reinterpret_cast<unsigned int *>(S.ccnt[0]);
     for (int i = tid; i < n; i += T) best[i] = 0;
     __syncthreads();
     for (int k0 = 0; k0 < K; k0 += T * kOctU) {
@@ -1149,11 +1168,11 @@ __global__ __launch_bounds__(T) void k_octree(PyrGeom G, const int *__restrict__
         int c = c0 + tid;
         int n = c < L.ncells ? ccnt_in[c] : 0;
         int base = block_excl_scan<T>(n, S.scan, &tot);
-        if (c < L.ncells) S.ccnt[c] = K + base;  // ncells <= MAXN*4 checked on the host
+        if (c < L.ncells) S.ccnt[0][c] = K + base;  // ncells <= MAXN*4 checked on the host
         K += tot;
     }
     __syncthreads();
-    if (K <= kOctKeysLds)
+    if (K <= oct_keys_lds<MAXN>())
         octree_body<MAXN, true, T>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
     else
         octree_body<MAXN, false, T>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
