@@ -818,9 +818,22 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
 #define knode(k) (*(INLDS ? &S.lnode[k] : &gnode[k]))
     const int tid = threadIdx.x;
     const int N = L.quota;
-    int tot;
-    // gather the per-cell survivor lists into one array in reference order: flat loop over the K keys,
-    // owning cell by binary search over the exclusive offsets in S.ccnt (loads stay independent)
+    // ---- initial nodes (:543-585); their key counters live in counter buffer 1 (buffer 0 holds the cell offsets) ----
+    const int nIni = L.nIni;
+    const int height = L.maxBY - 16;
+    int *RC = S.ccnt[1];
+    for (int i = tid; i < nIni; i += T) {
+        S.x0[0][i] = (short)(int)__fmul_rn(L.hX, (float)i);
+        S.x1[0][i] = (short)(int)__fmul_rn(L.hX, (float)(i + 1));
+        S.y0[0][i] = 0;
+        S.y1[0][i] = (short)height;
+        RC[i] = 0;
+    }
+    __syncthreads();   // also publishes the cell offsets the caller wrote
+    // gather the per-cell survivor lists into one array in reference order (flat loop over the K keys, owning cell by
+    // binary search over the exclusive offsets, loads stay independent) and, in the same pass, file every key under
+    // its initial node; with a handful of initial nodes all keys would hammer the same few LDS counters, so a
+    // wavefront adds its keys up with ballots first
     for (int k0 = 0; k0 < K; k0 += T * 4) {
         uint32_t v[4];
 #pragma unroll
@@ -828,7 +841,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
             const int k = k0 + u * T + tid;
             v[u] = 0;
             if (k < K) {
-                int lo = 0, hi = L.ncells - 1;      // last cell c with S.ccnt[0][c] <= k
+                int lo = 0, hi = L.ncells - 1;      // last cell c with offset[c] <= k
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
                     if (S.ccnt[0][mid] <= k) lo = mid; else hi = mid - 1;
@@ -839,57 +852,49 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = k0 + u * T + tid;
-            if (k < K) keys(k) = v[u];
-        }
-    }
-    __syncthreads();
-
-    // ---- initial nodes (:543-585) ----
-    const int nIni = L.nIni;
-    const int height = L.maxBY - 16;
-    for (int i = tid; i < nIni; i += T) {
-        S.x0[0][i] = (short)(int)__fmul_rn(L.hX, (float)i);
-        S.x1[0][i] = (short)(int)__fmul_rn(L.hX, (float)(i + 1));
-        S.y0[0][i] = 0;
-        S.y1[0][i] = (short)height;
-        S.ccnt[0][i] = 0;
-    }
-    __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += T * kOctU) {
-        uint32_t kv[kOctU];
+            const bool ok = k < K;
+            const int bin = min((int)__fdiv_rn((float)(v[u] & 0xfffu), L.hX), nIni - 1);
+            if (ok) { keys(k) = v[u]; knode(k) = (unsigned short)bin; }
+            if (nIni <= 4) {
 #pragma unroll
-        for (int u = 0; u < kOctU; ++u) { const int k = k0 + u * T + tid; kv[u] = k < K ? keys(k) : 0u; }
-#pragma unroll
-        for (int u = 0; u < kOctU; ++u) {
-            const int k = k0 + u * T + tid;
-            if (k < K) {
-                const int bin = min((int)__fdiv_rn((float)(kv[u] & 0xfffu), L.hX), nIni - 1);
-                knode(k) = (unsigned short)bin;
-                atomicAdd(&S.ccnt[0][bin], 1);
-            }
-        }
-    }
-    __syncthreads();
-    int n = 0;  // list size
-    {
-        // drop empty initial nodes, keep order
-        int carry = 0;
-        for (int i0 = 0; i0 < nIni; i0 += T) {
-            int i = i0 + tid;
-            int c = i < nIni ? S.ccnt[0][i] : 0;
-            int pos = carry + block_excl_scan<T>(c > 0, S.scan, &tot);
-            if (i < nIni) {
-                S.nmap[i] = pos;
-                if (c > 0) {
-                    S.x0[1][pos] = S.x0[0][i]; S.x1[1][pos] = S.x1[0][i];
-                    S.y0[1][pos] = S.y0[0][i]; S.y1[1][pos] = S.y1[0][i];
-                    S.cnt[1][pos] = c;
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long mk = __ballot(ok && bin == j);
+                    if ((tid & 63) == 0 && mk) atomicAdd(&RC[j], __popcll(mk));
                 }
+            } else if (ok) {
+                atomicAdd(&RC[bin], 1);
             }
-            carry += tot;
         }
-        n = carry;
-        __syncthreads();
+    }
+    __syncthreads();
+    // one wavefront drops the empty initial nodes (order kept) and clears the first pass's child counters
+    if (tid < 64) {
+        const int lane = tid;
+        const int per = (nIni + 63) >> 6;
+        const int i_lo = lane * per, i_hi = min(i_lo + per, nIni);
+        int ne = 0;
+        for (int i = i_lo; i < i_hi; ++i) ne += RC[i] > 0;
+        int incl = ne;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+        const int n0 = __shfl(incl, 63, 64);
+        int pos = incl - ne;
+        for (int i = i_lo; i < i_hi; ++i) {
+            const int c = RC[i];
+            S.nmap[i] = pos;
+            if (c > 0) {
+                S.x0[1][pos] = S.x0[0][i]; S.x1[1][pos] = S.x1[0][i];
+                S.y0[1][pos] = S.y0[0][i]; S.y1[1][pos] = S.y1[0][i];
+                S.cnt[1][pos] = c;
+                ++pos;
+            }
+        }
+        if (lane == 0) S.vars[0] = n0;
+        for (int i = lane; i < n0 * 4; i += 64) S.ccnt[0][i] = 0;
+    }
+    __syncthreads();
+    int n = S.vars[0];  // list size
+    if (n != nIni) {    // some initial node was empty: the keys' node labels shift
         for (int k0 = 0; k0 < K; k0 += T * kOctU) {
             int nd[kOctU];
 #pragma unroll
@@ -899,15 +904,11 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
 #pragma unroll
             for (int u = 0; u < kOctU; ++u) { const int k = k0 + u * T + tid; if (k < K) knode(k) = (unsigned short)nd[u]; }
         }
-        __syncthreads();
     }
     int cur = 1;
     int phase = 1;
     bool finish = (K == 0);
     int cb = 0;     // child-counter buffer of this pass
-    // the first pass's counters (the gather and the root binning used buffer 0 for other things)
-    for (int i = tid; i < n * 4; i += T) S.ccnt[0][i] = 0;
-    __syncthreads();
 
     // A pass = [all wavefronts] count the children of every expandable node over the keys -> barrier ->
     // [ONE wavefront] the node-table work: which nodes split, the new table in list order, where every created child and
@@ -1171,7 +1172,6 @@ __global__ __launch_bounds__(T) void k_octree(PyrGeom G, const int *__restrict__
         if (c < L.ncells) S.ccnt[0][c] = K + base;  // ncells <= MAXN*4 checked on the host
         K += tot;
     }
-    __syncthreads();
     if (K <= oct_keys_lds<MAXN>())
         octree_body<MAXN, true, T>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
     else
