@@ -1487,7 +1487,6 @@ constexpr int kWinRpi = 5;                    // rows per staging instruction (5
 constexpr int kWinLoads = 9;                  // 9 x 5 = 45 >= 43 rows
 constexpr int kWinWords = kWinRows * kWinDw + 7;   // + the dwords the last column group reads past the last row
 constexpr int kHPairs = 22, kHGroups = 10;    // row-pass results: 22 pair-rows x 10 groups of 4 columns (uint4 each)
-constexpr int kBPairs = 19, kBDw = 10;        // blurred patch: 38 rows (37 used) x 40 bytes
 
 __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restrict__ pyr, PyrGeom G,
                                                         const uint32_t *__restrict__ sel_kp,
@@ -1615,26 +1614,19 @@ __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restric
     float a, bsn;
     det_sincos(__fmul_rn(angle, factorPI), &a, &bsn);
     __builtin_amdgcn_wave_barrier();                     // DS operations of a wavefront execute in order
-    // ---- column pass: blurred patch rows 2p, 2p+1 (patch row r = window rows r .. r+6), written over the window tile ----
-#pragma unroll 1
-    for (int it = lane; it < kBPairs * kBDw; it += 64) {
-        const int p = (it * 205) >> 11, g = it - p * kBDw;
-        const uint4 P0 = hs[p * kHGroups + g], P1 = hs[(p + 1) * kHGroups + g], P2 = hs[(p + 2) * kHGroups + g], P3 = hs[(p + 3) * kHGroups + g];
-        const uint32_t a0[4] = {P0.x, P0.y, P0.z, P0.w}, a1[4] = {P1.x, P1.y, P1.z, P1.w},
-                       a2[4] = {P2.x, P2.y, P2.z, P2.w}, a3[4] = {P3.x, P3.y, P3.z, P3.w};
-        uint32_t acce[4], acco[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acce[j] = udot2(a0[j], w01, udot2(a1[j], w23, udot2(a2[j], w45, udot2(a3[j], w6l, 32768u))));
-            acco[j] = udot2(a1[j], w12, udot2(a2[j], w34, udot2(a3[j], w56, udot2(a0[j], w0h, 32768u))));
-        }
-        win[(2 * p) * kBDw + g] = sat_pk_u8(__builtin_amdgcn_perm(acce[1], acce[0], 0x07060302u)) |
-                                  (sat_pk_u8(__builtin_amdgcn_perm(acce[3], acce[2], 0x07060302u)) << 16);
-        win[(2 * p + 1) * kBDw + g] = sat_pk_u8(__builtin_amdgcn_perm(acco[1], acco[0], 0x07060302u)) |
-                                      (sat_pk_u8(__builtin_amdgcn_perm(acco[3], acco[2], 0x07060302u)) << 16);
-    }
-    __builtin_amdgcn_wave_barrier();
-    const uint8_t *cb = reinterpret_cast<const uint8_t *>(win) + 18 * (kBDw * 4) + 18;   // blurred patch byte of the keypoint
+    // ---- column pass on demand: a descriptor test needs the blurred patch at two points only, so the 7-tap column sum
+    // is evaluated right at the 8 sample points of a lane (4 dwords of row sums -- two window rows each -- against the
+    // tap pairs of the point's row parity) instead of over all 37 x 37 patch pixels first ----
+    const uint32_t *hd = reinterpret_cast<const uint32_t *>(hs);   // row sums as dwords: [pair-row][column], 40 columns
+    auto blurred = [&](int r, int c) -> int {
+        const int R = r + 18, C = c + 18;                  // patch row / column; window rows R .. R + 6
+        const uint32_t *p = hd + madi24(R >> 1, kHGroups * 4, C);
+        const uint32_t d0 = p[0], d1 = p[kHGroups * 4], d2 = p[2 * kHGroups * 4], d3 = p[3 * kHGroups * 4];
+        const bool odd = (R & 1) != 0;
+        const uint32_t acc = udot2(d0, odd ? w0h : w01, udot2(d1, odd ? w12 : w23, udot2(d2, odd ? w34 : w45,
+                                   udot2(d3, odd ? w56 : w6l, 32768u))));
+        return min((int)(acc >> 16), 255);                 // the taps sum to 257: saturate like the byte store did
+    };
     unsigned long long bits[4];
     int t0v[4], t1v[4];
 #pragma unroll
@@ -1644,8 +1636,8 @@ __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restric
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, bsn)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, bsn), __fmul_rn(py1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, bsn)));
-        t0v[j] = cb[__mul24(r0, kBDw * 4) + c0];
-        t1v[j] = cb[__mul24(r1, kBDw * 4) + c1];
+        t0v[j] = blurred(r0, c0);
+        t1v[j] = blurred(r1, c1);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) bits[j] = __ballot(t0v[j] < t1v[j]);
