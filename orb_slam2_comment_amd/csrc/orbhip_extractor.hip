@@ -2005,7 +2005,6 @@ static int ensure_batch(orbhip_extractor *e, int batch)
     const PyrGeom &G = e->G;
     const size_t B = (size_t)batch;
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_pyr, B * G.frame_bytes));
-    ORBHIP_HIP_CHECK(hipMalloc(&e->d_blur, B * G.frame_bytes));
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_cell_cnt, B * std::max(G.ncells_total, 1) * sizeof(int)));
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_cell_kp, B * std::max(G.ncells_total, 1) * G.slot_cap * sizeof(uint32_t)));
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_keys, B * G.cand_cap_total * sizeof(uint32_t)));
@@ -2026,7 +2025,9 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     const PyrGeom &G = e->G;
     hipStream_t s = e->stream;
     // per-frame internal buffers of this launch
-    uint8_t *const b_pyr = e->d_pyr + (size_t)frame0 * G.frame_bytes, *const b_blur = e->d_blur + (size_t)frame0 * G.frame_bytes;
+    static const bool dev_sep = getenv("ORBHIP_SEPARATE_BLUR") != nullptr;   // development switch: blur kernel + unfused describe
+    if (dev_sep && !e->d_blur) ORBHIP_HIP_CHECK(hipMalloc(&e->d_blur, (size_t)e->batch_cap * G.frame_bytes));
+    uint8_t *const b_pyr = e->d_pyr + (size_t)frame0 * G.frame_bytes, *const b_blur = e->d_blur ? e->d_blur + (size_t)frame0 * G.frame_bytes : nullptr;
     int *const b_cell_cnt = e->d_cell_cnt + (size_t)frame0 * std::max(G.ncells_total, 1);
     uint32_t *const b_cell_kp = e->d_cell_kp + (size_t)frame0 * std::max(G.ncells_total, 1) * G.slot_cap;
     uint32_t *const b_keys = e->d_keys + (size_t)frame0 * G.cand_cap_total;
@@ -2110,7 +2111,6 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     // The blur only needs the pyramid.  Forking it onto a second stream beside FAST/octree was measured: it buys
     // nothing once two pipelines (handles) run concurrently and makes throughput depend on how the runtime maps
     // streams to hardware queues (122 k vs 136 k frames/s run to run), so it stays in order on this stream.
-    static const bool dev_sep = getenv("ORBHIP_SEPARATE_BLUR") != nullptr;   // development switch: blur kernel + unfused describe
     if ((sm & 8) && dev_sep) hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, b_pyr, b_blur, G,
                                                 e->d_tiles, e->blurw);
     if (prof) (void)hipEventRecord(ev[4], s);
@@ -2579,8 +2579,10 @@ int orbhip_pyramid_level_download(orbhip_extractor *e, int frame, int level, int
 int orbhip_blurred_level_download(orbhip_extractor *e, int frame, int level, uint8_t *dst, int dst_stride)
 {
     if (e && e->bound && !e->blur_valid && e->last_batch > 0) {
-        // the pipeline blurs patches inside the descriptor kernel; the full blurred planes are produced on request
+        // the pipeline blurs patches inside the descriptor kernel; the full blurred planes (and their buffer) are
+        // produced on request
         ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+        if (!e->d_blur) ORBHIP_HIP_CHECK(hipMalloc(&e->d_blur, (size_t)e->batch_cap * e->G.frame_bytes));
         hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), e->last_batch), dim3(256), 0, e->stream, e->d_pyr, e->d_blur, e->G,
                            e->d_tiles, e->blurw);
         ORBHIP_HIP_CHECK(hipGetLastError());
