@@ -467,6 +467,7 @@ __global__ __launch_bounds__(256) void k_pyr_rows(uint8_t *__restrict__ pyr, uin
 }
 
 constexpr int kSubMax = 72;              // max (wCell+6), (hCell+6)
+constexpr int kFastLead = 1;             // k_fast_cells: LDS column of sub-image x is x + kFastLead + 4
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
@@ -1921,7 +1922,7 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
             msh = std::max(msh, c.y1 - c.y0);
             mdh = std::max(mdh, c.y1 - c.y0 - 6);
             mdw = std::max(mdw, c.x1 - c.x0 - 6);
-            mndw = std::max(mndw, ((c.x0 & 3) + (c.x1 - c.x0) + 3) >> 2);
+            mndw = std::max(mndw, (kFastLead + (c.x1 - c.x0) + 3) >> 2);
         }
         FastLds &F2 = e->fast_lds;
         // compile-time row stride (odd: rows rotate over the LDS banks): staged dwords + one real dword on the left
@@ -1942,7 +1943,12 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         for (const CellDesc &c : e->cells) {
             const LevelGeom &Lc = G.lv[c.level];
             FastCell f; memset(&f, 0, sizeof(f));
-            const int a = c.x0 & 3, gxb = c.x0 - a, sw = c.x1 - c.x0, shh = c.y1 - c.y0;
+            // The sub-image is staged so that its first detection column (x0 + 3) lands on a dword boundary of the LDS row
+            // whatever x0 is: LDS column 0 = x0 - 5 (global rows are read with byte-unaligned dword loads), i.e. the
+            // kernel's "a" is the constant 1 and the first centre column is LDS column 8.  A row of 31 or 32 detection
+            // columns is then 8 four-pixel groups, never 9 -- for 32 rows that is 256 dense items = exactly 4 rounds of
+            // the wavefront instead of 4.5 (5).
+            const int a = kFastLead, gxb = c.x0 - a, sw = c.x1 - c.x0, shh = c.y1 - c.y0;
             f.src_off = Lc.plane_off + (unsigned)((kEdge + c.y0) * Lc.pitch + kPadL + gxb - 4);
             f.pitch = (unsigned short)Lc.pitch; f.sw = (unsigned char)sw; f.sh = (unsigned char)shh; f.a = (unsigned char)a;
             f.kpx = (short)(c.offx - 4 - a); f.kpy = (short)(c.offy + 3);
