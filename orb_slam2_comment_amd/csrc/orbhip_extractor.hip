@@ -620,8 +620,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     if (P.dev == 4) { if (lane == 0) cell_cnt[out_cell] = (int)simg[lane] & 0; return; }   // development: staging floor
 
     // column groups: group g covers LDS cols 4g..4g+3; valid centre cols [c_lo, c_hi)
-    const int a = cd.a;
-    const int c_lo = a + 4 + 3, c_hi = c_lo + dw;
+    constexpr int a = kFastLead;                        // every cell is staged with the same lead (bind_geometry)
+    constexpr int c_lo = a + 4 + 3;                     // = 8: the first centre column sits on a dword boundary
+    const int c_hi = c_lo + dw;
     const int g_lo = c_lo >> 2, g_hi = (c_hi - 1) >> 2;
     const int ngrp = g_hi - g_lo + 1;
     const int nwork = ngrp * dh;                        // (row, group) work items, row-major
