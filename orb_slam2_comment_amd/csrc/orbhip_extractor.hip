@@ -44,11 +44,18 @@ __device__ __forceinline__ void xcd_remap(int &unit, int &frame)
     unit = (int)(lin2 - (unsigned)frame * gridDim.x);
 }
 
+// Sum over the wavefront, returned to every lane as a wave-uniform value.  DPP butterfly inside each row of 16 lanes
+// (two quad permutes, half mirror, mirror), then the row sums travel with row_bcast:15 / row_bcast:31 and lane 63 holds
+// the total: six v_add with a DPP operand instead of six ds_bpermute round trips through the LDS crossbar.
 __device__ __forceinline__ int wave_reduce_add(int v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // row_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Exclusive scan of one int per thread over a T-thread block (T = 256, 512 or 1024).  `sh` = T / 64 ints of LDS.
