@@ -63,6 +63,49 @@ struct CellDesc {
     short pad;
 };
 
+// Wave-level scan / reductions on the DPP data path (no LDS crossbar round trips).  Rows are 16 lanes: Hillis-Steele
+// inside a row with row_shr (lanes shifted in from outside the row contribute 0), then the row totals travel with
+// row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3).
+__device__ __forceinline__ int wave_incl_scan_add(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+    return v;
+}
+// sum over the wavefront, wave-uniform result (butterfly inside the rows, then the row totals; lane 63 holds the sum)
+__device__ __forceinline__ int wave_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // row_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// minimum over each row of 16 lanes, in every lane of the row (butterfly on the DPP data path)
+__device__ __forceinline__ int row16_min(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    return v;
+}
+// minimum over the wavefront, wave-uniform result
+__device__ __forceinline__ int wave_min(int v)
+{
+    v = row16_min(v);
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     // BORDER_REFLECT_101; |overshoot| < len is guaranteed by the callers (19-px border)

@@ -44,19 +44,7 @@ __device__ __forceinline__ void xcd_remap(int &unit, int &frame)
     unit = (int)(lin2 - (unsigned)frame * gridDim.x);
 }
 
-// Sum over the wavefront, returned to every lane as a wave-uniform value.  DPP butterfly inside each row of 16 lanes
-// (two quad permutes, half mirror, mirror), then the row sums travel with row_bcast:15 / row_bcast:31 and lane 63 holds
-// the total: six v_add with a DPP operand instead of six ds_bpermute round trips through the LDS crossbar.
-__device__ __forceinline__ int wave_reduce_add(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // row_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return __builtin_amdgcn_readlane(v, 63);
-}
+__device__ __forceinline__ int wave_reduce_add(int v) { return wave_sum(v); }
 
 // Exclusive scan of one int per thread over a T-thread block (T = 256, 512 or 1024).  `sh` = T / 64 ints of LDS.
 // Returns the exclusive prefix; *total receives the block sum.  Ends with a barrier.
@@ -64,12 +52,7 @@ template <int T>
 __device__ __forceinline__ int block_excl_scan(int v, int *sh, int *total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
+    const int incl = wave_incl_scan_add(v);
     __syncthreads();  // protect sh reuse across consecutive calls
     if (lane == 63) sh[wave] = incl;
     __syncthreads();
@@ -884,9 +867,8 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
         int ne = 0;
         for (int i = i_lo; i < i_hi; ++i) ne += RC[i] > 0;
         int incl = ne;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
-        const int n0 = __shfl(incl, 63, 64);
+        incl = wave_incl_scan_add(incl);
+        const int n0 = __builtin_amdgcn_readlane(incl, 63);
         int pos = incl - ne;
         for (int i = i_lo; i < i_hi; ++i) {
             const int c = RC[i];
@@ -990,9 +972,8 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
                 int e_cnt = 0;
                 for (int i = i_lo; i < i_hi; ++i) e_cnt += S.cnt[cur][i] > 1;
                 int incl = e_cnt;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
-                m = __shfl(incl, 63, 64);
+                incl = wave_incl_scan_add(incl);
+                m = __builtin_amdgcn_readlane(incl, 63);
                 if (phase == 1) {
                     int r = incl - e_cnt;
                     for (int i = i_lo; i < i_hi; ++i) {
@@ -1013,8 +994,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
                     sum += (CC[4 * nd] > 0) + (CC[4 * nd + 1] > 0) + (CC[4 * nd + 2] > 0) + (CC[4 * nd + 3] > 0);
                 }
                 int incl = sum;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+                incl = wave_incl_scan_add(incl);
                 int run = incl - sum, jf = 0x7fffffff;
                 for (int j = j_lo; j < j_hi; ++j) {
                     const int nd = S.ord[j];
@@ -1022,8 +1002,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
                     S.cincl[j] = run;
                     if (phase == 2 && jf == 0x7fffffff && n + run - (j + 1) >= N) jf = j;
                 }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) jf = min(jf, __shfl_xor(jf, off, 64));
+                jf = wave_min(jf);
                 J = jf == 0x7fffffff ? m - 1 : jf;
             }
             __builtin_amdgcn_wave_barrier();
@@ -1034,8 +1013,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
                 int surv_cnt = 0;
                 for (int i = i_lo; i < i_hi; ++i) { const int r = S.rnk[i]; surv_cnt += !(r != 0xffff && r <= J); }
                 int incl = surv_cnt;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+                incl = wave_incl_scan_add(incl);
                 int spos = incl - surv_cnt;
                 for (int i = i_lo; i < i_hi; ++i) {
                     const int r = S.rnk[i];
@@ -1070,8 +1048,7 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
                 }
             }
             // G: bookkeeping (:669-673, :734)
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) nToExpand += __shfl_xor(nToExpand, off, 64);
+            nToExpand = wave_sum(nToExpand);
             const int n_new = Gc + (n - (m > 0 ? J + 1 : 0));
             int fin = 0, ph = phase;
             if (n_new >= N || n_new == prevSize) fin = 1;

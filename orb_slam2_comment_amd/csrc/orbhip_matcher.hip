@@ -60,9 +60,7 @@ __device__ __forceinline__ int hamming256(const uint32_t *a, const uint32_t *b)
 
 __device__ __forceinline__ int wave_reduce_add_i(int v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    return wave_sum(v);
 }
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
@@ -126,8 +124,7 @@ __device__ __forceinline__ void grid_build_body(DevFrame F, int *__restrict__ ce
     for (int k = 0; k < PER; ++k) { local[k] = s_cnt[tid * PER + k]; sum += local[k]; }
     int incl = sum;
     const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+    incl = wave_incl_scan_add(incl);
     if (lane == 63) s_scan[wave] = incl;
     __syncthreads();
     int base = incl - sum;
@@ -226,9 +223,8 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const int *__
         }
         // exclusive prefix of the column populations over the wave
         int incl = ncand;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
-        const int nrec = __shfl(incl, 63, 64);
+        incl = wave_incl_scan_add(incl);
+        const int nrec = __builtin_amdgcn_readlane(incl, 63);
         const int excl = incl - ncand;
         for (int r0 = 0; r0 < nrec; r0 += 64) {
             // scatter: flat record t of this chunk comes from CSR position spos[t - r0]
@@ -1344,11 +1340,7 @@ __global__ __launch_bounds__(1024) void k_grid_csr(DevFrame F, Batch B, int *__r
     const int v0 = cnt[c0], v1 = cnt[c0 + 1], v2 = cnt[c0 + 2];
     int incl = v0 + v1 + v2;
     const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
+    incl = wave_incl_scan_add(incl);
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
     int base = 0;

@@ -42,12 +42,8 @@ struct VocBatch {
 
 __device__ __forceinline__ int group16_min(int v)
 {
-    // 16-lane groups are aligned to DPP rows: xor 8/4/2/1 stay inside the group
-    v = min(v, __shfl_xor(v, 8, 64));
-    v = min(v, __shfl_xor(v, 4, 64));
-    v = min(v, __shfl_xor(v, 2, 64));
-    v = min(v, __shfl_xor(v, 1, 64));
-    return v;
+    // 16-lane groups are DPP rows: the butterfly never leaves the group and needs no LDS crossbar round trip
+    return orbhip::row16_min(v);
 }
 
 // One 16-lane group per feature.  key = distance * 32 + child position, so the group minimum is the reference's
