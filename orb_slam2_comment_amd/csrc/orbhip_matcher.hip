@@ -63,14 +63,27 @@ __device__ __forceinline__ int wave_reduce_add_i(int v)
     return wave_sum(v);
 }
 
+// 64-bit minimum over the wavefront (wave-uniform result): the same DPP butterfly + row broadcasts as wave_sum, both
+// halves of the key travelling together
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        unsigned long long o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
+#define ORBHIP_MIN64_STEP(ctrl, rmask)                                                                        \
+    {                                                                                                         \
+        const uint32_t lo_ = (uint32_t)v, hi_ = (uint32_t)(v >> 32);                                          \
+        const uint32_t ol_ = (uint32_t)__builtin_amdgcn_update_dpp((int)lo_, (int)lo_, ctrl, rmask, 0xf, false); \
+        const uint32_t oh_ = (uint32_t)__builtin_amdgcn_update_dpp((int)hi_, (int)hi_, ctrl, rmask, 0xf, false); \
+        const unsigned long long o_ = ((unsigned long long)oh_ << 32) | ol_;                                  \
+        v = o_ < v ? o_ : v;                                                                                  \
     }
-    return v;
+    ORBHIP_MIN64_STEP(0xB1, 0xf)
+    ORBHIP_MIN64_STEP(0x4E, 0xf)
+    ORBHIP_MIN64_STEP(0x141, 0xf)
+    ORBHIP_MIN64_STEP(0x140, 0xf)
+    ORBHIP_MIN64_STEP(0x142, 0xa)
+    ORBHIP_MIN64_STEP(0x143, 0xc)
+#undef ORBHIP_MIN64_STEP
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), 63) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
 }
 
 // Visiting-order key of every train keypoint, (posX*48+posY) << 20 | index, or kNoCell when PosInGrid rejects it
