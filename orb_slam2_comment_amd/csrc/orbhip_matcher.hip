@@ -1886,29 +1886,27 @@ __global__ __launch_bounds__(256) void k_stereo_cull(int nl, const int *__restri
     const int nd = s_nd;
     if (nd == 0) { if (tid == 0) *out_n = 0; return; }
     const int target = nd / 2;
-    // rank counting over an LDS copy of the SAD list (broadcast reads); lists longer than the LDS copy fall
-    // back to reading HBM
+    // median = the (nd/2)-th smallest valid SAD (src/Frame.cc:628-630 sorts the (SAD, index) pairs and takes the middle
+    // one; only its value is used).  One wavefront finds it by bisection on the value: count(d <= mid) over an LDS copy
+    // of the list with a DPP wave sum per probe -- 16 probes, no barrier; the O(n^2) rank count this replaces took
+    // 130 us per 64 pairs.  Lists longer than the LDS copy are read from HBM.
     __shared__ int s_sad[kResolveMax];
     const bool in_lds = nl <= kResolveMax;
     if (in_lds) for (int i = tid; i < nl; i += 256) s_sad[i] = sad[i];
     __syncthreads();
-    for (int i = tid; i < nl; i += 256) {
-        const int d = in_lds ? s_sad[i] : sad[i];
-        if (d < 0) continue;
-        int rank = 0;
-        if (in_lds) {
-#pragma unroll 8
-            for (int j = 0; j < nl; ++j) {
-                const int dj = s_sad[j];
-                rank += (dj >= 0) && (dj < d || (dj == d && j < i));
+    if (tid < 64) {
+        int lo = 0, hi = 11 * 11 * 510;        // L1 norm of two 11 x 11 byte windows, each minus its centre pixel
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+            for (int i = tid; i < nl; i += 64) {
+                const int d = in_lds ? s_sad[i] : sad[i];
+                c += (d >= 0) && (d <= mid);
             }
-        } else {
-            for (int j = 0; j < nl; ++j) {
-                const int dj = sad[j];
-                rank += (dj >= 0) && (dj < d || (dj == d && j < i));
-            }
+            c = wave_sum(c);
+            if (c > target) hi = mid; else lo = mid + 1;
         }
-        if (rank == target) s_med = d;
+        if (tid == 0) s_med = lo;
     }
     __syncthreads();
     const float median = (float)s_med;
