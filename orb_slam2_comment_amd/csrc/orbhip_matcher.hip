@@ -922,13 +922,16 @@ __global__ __launch_bounds__(64) void k_resolve(int mode, DevFrame F, const orbh
 // candidate per query, no blocking, rotation cull, output per query) ---------------------------------------------
 // The sequential reference loop hands every query, in index order, the first candidate of its list (sorted by
 // (distance, visiting order)) that is neither taken on entry nor already held by an accepted, observed query with a
-// smaller index.  That is serial dictatorship, and its outcome is the unique stable matching of "queries prefer list
-// order, slots prefer the smaller query index", which deferred acceptance reaches from any proposal order: every round
-// all unsettled queries propose (atomicMin on the slot's holder) to the first entry of their list that no smaller query
-// holds.  A slot's holder only ever gets smaller and nobody gives a slot up voluntarily (a larger distance only lowers
-// the chance of acceptance; for the ratio test of mode 1 the second candidate only moves away, which can turn a
-// rejection into an acceptance but never the reverse), so each query's list cursor is monotone: the total walk is the
-// list length, not list length x rounds.  One workgroup per pair, state in LDS, one barrier per round.
+// smaller index.  That is serial dictatorship.
+//  * Modes 0 / 4 (frame-to-frame search, triangulation): acceptance depends on the first usable entry alone, so nobody
+//    ever gives a held slot up, and the outcome is the unique stable matching of "queries prefer list order, slots
+//    prefer the smaller query index", which deferred acceptance reaches from any proposal order: unsettled queries
+//    propose (atomicMin on the slot's holder) to the first entry no smaller query holds; a holder only ever gets
+//    smaller, so each query's list cursor is monotone and the total walk is the list length, not list length x rounds.
+//  * Mode 1 (map points): the ratio test applies only when best and second best share a level, so losing the second
+//    candidate to a smaller query can turn an acceptance into a rejection -- holders are not monotone.  There the
+//    rounds re-pick every query against the previous round's claims and rebuild the claims (fixed-point iteration).
+// One workgroup per pair, state in LDS.
 // State of the parallel resolve.  Up to kResolveMax train keypoints and queries it lives in LDS (GS = false); beyond
 // that the same arrays are carved out of an HBM workspace (GS = true: same code, global loads / atomics).
 struct ResolveParState {
@@ -1050,6 +1053,8 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     };
     unsigned short *wl_next = nullptr;   // set by the event-driven rounds
     int *wl_count = nullptr;
+    int *claim = holder;                 // where an accepted, observed query files its claim
+    bool claims_rebuilt = false;         // mode 1: the claims are rebuilt from scratch every round
     auto step = [&](int i) -> bool {
         const int c = S.q_cnt[i];
         int newc = -1;
@@ -1064,7 +1069,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                     return list[e];
                 };
                 // four entries per trip: their eight LDS reads (taken, holder) are in flight together
-                int e1 = cur1[i];
+                int e1 = mode == 1 ? 0 : cur1[i];
                 while (e1 < c) {
                     const unsigned long long v0 = entry(e1), v1 = entry(e1 + 1), v2 = entry(e1 + 2), v3 = entry(e1 + 3);
                     const bool a0 = !held_by_smaller((int)(v0 & 0xfffffu), i);
@@ -1078,14 +1083,12 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                     e1 += 4;
                 }
                 e1 = min(e1, c);
-                cur1[i] = (unsigned short)e1;
+                if (mode != 1) cur1[i] = (unsigned short)e1;
                 if (mode == 1 && e1 < c) {
-                    int e2 = max((int)cur2[i], e1 + 1);
-                    for (; e2 < c; ++e2) {
+                    for (int e2 = e1 + 1; e2 < c; ++e2) {
                         const unsigned long long v = entry(e2);
                         if (!held_by_smaller((int)(v & 0xfffffu), i)) { k2 = v; break; }
                     }
-                    cur2[i] = (unsigned short)e2;
                 }
             } else {       // unsorted (more than 64 candidates): smallest and second smallest available key
                 for (int e = 0; e < -c; ++e) {
@@ -1106,10 +1109,11 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                 if (acc) newc = bestIdx;
             }
         }
-        if (newc == S.choice[i]) return false;
+        const bool changed = newc != S.choice[i];
+        if (!changed && !claims_rebuilt) return false;
         S.choice[i] = newc;
         if (newc >= 0 && S.q_obs[i]) {
-            const int old = atomicMin(&holder[newc], i);
+            const int old = atomicMin(&claim[newc], i);
             // event-driven rounds: whoever loses the slot steps again -- me if a smaller query got there first, the
             // previous holder if I displaced it
             if (wl_next) {
@@ -1117,7 +1121,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
                 if (again >= 0) wl_next[atomicAdd(wl_count, 1)] = (unsigned short)again;
             }
         }
-        return true;
+        return changed;
     };
     if (mode != 1) {
         // Event-driven rounds (no second candidate, so a query's choice can only change when it loses its slot): the
@@ -1147,25 +1151,27 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
             for (int i = tid; i < nq; i += T) if (!S.q_obs[i]) step(i);
         if (tid == 0) { atomicAdd(&g_resolve_stats[0], 1u); atomicAdd(&g_resolve_stats[1], (unsigned)rounds + 1); atomicMax(&g_resolve_stats[2], (unsigned)rounds + 1); }
     } else {
-        // mode 1 (second candidate, ratio test): a wavefront keeps stepping its own queries until a step changes none of
-        // them; the barrier only serves the termination test (a round in which no query of the workgroup changed).
-        // Three "changed" flags in rotation (vars[0], [3], [4]): a round raises its own and resets the next one's.
-        constexpr int kLocalSteps = 16;
-        int f_cur = 0, f_nxt = 3;
-        for (int round = 0; round <= 65 * nq + 2; ++round) {   // every round but the last moves at least one cursor
-            int *flag = &S.vars[f_cur];
-            if (tid == 0) S.vars[f_nxt] = 0;
-            bool wave_changed = false;
-            for (int ls = 0; ls < kLocalSteps; ++ls) {
-                bool ch = false;
-                for (int i = tid; i < nq; i += T) ch |= step(i);
-                if (!__any(ch)) break;
-                wave_changed = true;
-            }
-            if (wave_changed && (tid & 63) == 0) *flag = 1;
+        // mode 1 (map points: second candidate, ratio test among candidates of the same level).  Here a query CAN have
+        // to give a held slot up: when its second candidate is taken by a smaller query, the next one may sit on the best
+        // candidate's level and fail the ratio test that the previous pair never had to take -- holders are not
+        // monotone, so no deferred acceptance.  The sequential loop is still the unique solution of "every query picks
+        // against the claims of the smaller queries", found by fixed-point iteration: each round all queries re-pick
+        // against the claims of the previous round and the claims are rebuilt from scratch (query i is final once all
+        // j < i are: at most nq + 1 rounds, a handful in practice).
+        int *own_cur = S.owner[0], *own_nxt = S.owner[1];
+        claims_rebuilt = true;
+        for (int round = 0; round <= nq + 1; ++round) {
+            if (tid == 0) S.vars[0] = 0;
+            for (int c = tid; c < n; c += T) own_nxt[c] = INT_MAX;
             __syncthreads();
-            const int changed = *flag;
-            f_cur = f_nxt; f_nxt = f_nxt == 0 ? 3 : f_nxt == 3 ? 4 : 0;
+            holder = own_cur; claim = own_nxt;
+            bool ch = false;
+            for (int i = tid; i < nq; i += T) ch |= step(i);
+            if (ch) S.vars[0] = 1;
+            __syncthreads();
+            const int changed = S.vars[0];
+            { int *t_ = own_cur; own_cur = own_nxt; own_nxt = t_; }
+            __syncthreads();
             if (!changed) {
                 if (tid == 0) { atomicAdd(&g_resolve_stats[0], 1u); atomicAdd(&g_resolve_stats[1], (unsigned)round + 1); atomicMax(&g_resolve_stats[2], (unsigned)round + 1); }
                 break;

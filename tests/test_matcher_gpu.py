@@ -3,6 +3,8 @@ Stated tolerance (BASELINE north_star: "match sets within a stated tolerance"): 
 assignment arrays and match counts must be IDENTICAL (integer Hamming distances, same visiting
 order); mvuRight / mvDepth must agree to 1e-6 relative (they are produced by the same float
 operation sequence, so in practice they are bit-identical)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -794,3 +796,17 @@ def test_undistort_keypoints(env):
     got1 = dk[1, :100].cpu().numpy().view(pkg.KP_DTYPE).reshape(-1)
     assert all(np.array_equal(got0[f], want[f]) for f in k.dtype.names)
     assert all(np.array_equal(got1[f], want[50:150][f]) for f in k.dtype.names)
+
+
+def test_randomised_parity_sweep():
+    """tools/stress_parity.py: random sizes, feature counts, scale factors, level counts, thresholds, observed / taken
+    patterns for the extractor and both SearchByProjection searches.  Seed 11 contains the case (605x581, 2 levels) in
+    which a map-point query has to give a held slot up because its second candidate changes level -- the reason the
+    map-point search resolves by fixed-point iteration and not by deferred acceptance."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "--cases", "24", "--seed", "11"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all cases passed" in r.stdout
