@@ -2555,10 +2555,15 @@ static int download_plane(orbhip_extractor *e, const uint8_t *base, int frame, i
     const int bo = with_border ? kEdge : 0;
     const int w = L.w + 2 * bo, h = L.h + 2 * bo;
     if (dst_stride < w) return ORBHIP_E_ARG;
-    const uint8_t *src = base + (size_t)frame * e->G.frame_bytes + L.plane_off + (size_t)(kEdge - bo) * L.pitch + (kPadL - bo);
+    // whole padded rows in one contiguous copy on the handle's stream, cropped on the host (a pitched 2-D copy into
+    // pageable memory goes through the runtime's rectangle-copy path, which was seen to deliver a stale plane about once
+    // in a thousand downloads of a randomised sweep)
+    const uint8_t *src = base + (size_t)frame * e->G.frame_bytes + L.plane_off + (size_t)(kEdge - bo) * L.pitch;
     ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    std::vector<uint8_t> rows((size_t)h * L.pitch);
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(rows.data(), src, rows.size(), hipMemcpyDeviceToHost, e->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
-    ORBHIP_HIP_CHECK(hipMemcpy2D(dst, dst_stride, src, L.pitch, w, h, hipMemcpyDeviceToHost));
+    for (int r = 0; r < h; ++r) memcpy(dst + (size_t)r * dst_stride, rows.data() + (size_t)r * L.pitch + (kPadL - bo), (size_t)w);
     return ORBHIP_OK;
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU: ORBextractor (stage by stage) and the two SearchByProjection searches against the
 oracle on random image sizes, feature counts, scale factors, level counts, thresholds, shifts, `taken` / `observed`
-patterns.  Complements the fixed-seed suite in tests/ (which covers every entry point); this one hunts for rare
+patterns, and Frame::ComputeStereoMatches on every third case.  Complements the fixed-seed suite in tests/ (which covers every entry point); this one hunts for rare
 geometry- or data-dependent mismatches.  Exit code 1 on the first mismatch (the failing case is printed).
 
   python tools/stress_parity.py [--cases 60] [--seed 1]
@@ -25,7 +25,7 @@ def main():
     args = ap.parse_args()
     import orb_slam2_comment_amd as pkg
     from oracle import oracle_py as O
-    from helpers import assert_kps_equal, assert_stagewise_equal, frame_bounds, synth_frame
+    from helpers import assert_kps_equal, assert_stagewise_equal, frame_bounds, synth_frame, synth_stereo
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
     for case in range(args.cases):
@@ -93,7 +93,25 @@ def main():
         n2, assign2 = m2.SearchByProjectionPoints(gv, q2, d0, taken)
         on2, oassign2 = O.search_by_projection_points(ov, q2, d0, taken, nnr)
         assert n2 == on2 and np.array_equal(assign2, oassign2), desc + " SearchByProjection(points)"
-        print("%s -> ok (%d / %d keypoints, %d / %d matches) [%.0f s]" % (desc, len(k0), len(k1), n, n2, time.time() - t0), flush=True)
+        ns = -1
+        if case % 3 == 0 and W >= 400 and H >= 200:
+            # Frame::ComputeStereoMatches on a synthetic rectified pair of the same size and extractor parameters
+            left, right = synth_stereo(seed, W, H)
+            eR = pkg.ORBextractor(nf, scale, nlev, ini, mn)
+            kl, dl = ext(left)
+            kr, dr = eR(right)
+            if len(kl) >= 8 and len(kr) >= 8:
+                mbf = np.float32(386.1448); mb = np.float32(mbf / np.float32(718.856))
+                ns, urr, dpp = pkg.ORBmatcher().ComputeStereoMatches(ext, eR, kl, dl, kr, dr, float(mbf), float(mb))
+                oL, oR = O.OracleExtractor(nf, scale, nlev, ini, mn), O.OracleExtractor(nf, scale, nlev, ini, mn)
+                okl, odl = oL.extract(left)
+                okr, odr = oR.extract(right)
+                lv_l = [np.ascontiguousarray(oL.level_padded(l))[19:-19, 19:-19] for l in range(nlev)]
+                lv_r = [np.ascontiguousarray(oR.level_padded(l))[19:-19, 19:-19] for l in range(nlev)]
+                t = oL.tables()
+                on3, our, odp = O.compute_stereo_matches(okl, odl, okr, odr, lv_l, lv_r, t["scale"], t["inv_scale"], float(mbf), float(mb))
+                assert ns == on3 and np.array_equal(urr, our) and np.array_equal(dpp, odp), desc + " ComputeStereoMatches"
+        print("%s -> ok (%d / %d keypoints, %d / %d matches, stereo %d) [%.0f s]" % (desc, len(k0), len(k1), n, n2, ns, time.time() - t0), flush=True)
     print("stress parity: all cases passed")
     return 0
 
