@@ -1234,6 +1234,224 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     if (tid == 0) *out_n = S.vars[1] - S.vars[2];
 }
 
+// ---- parallel resolve of SearchForInitialization (ORBmatcher.cc:405-520) -----------------------------------------
+// The reference visits the queries in index order; a candidate slot b is usable for query i iff no earlier accepted
+// query left a distance <= dist(i, b) on it (vMatchedDistance), the query takes its best usable candidate if it passes
+// TH_LOW and the ratio test against the second best usable one, and a later, closer query steals the slot (the loser is
+// NOT re-matched).  Every decision therefore depends only on the decisions of the queries with a smaller index: the
+// sequential result is the unique fixed point of "every query decides against the claims of the smaller queries", and
+// Jacobi iteration reaches it (query i is final once all j < i are).  A round rebuilds, per slot, a linked list of this
+// round's claimants (atomicExch on the slot's head); the next round's queries walk the list of a candidate slot and take
+// the minimum claimed distance among the claimants with a smaller index.  One workgroup per pair, state in LDS
+// (n, nq <= 4096: the limit the entry points already state); the serial replay (k_resolve mode 2) this replaces took
+// about 200 ns per query on one wavefront.
+struct InitState {
+    int *q_cnt; float *q_angle, *t_angle;
+    uint32_t *claim[2];          // per query: distance << 20 | slot, or kNoClaim
+    int *head[2];                // per slot: a claimant of this round, -1 if none
+    unsigned short *next[2];     // per query: next claimant of the same slot, 0xffff = end
+    unsigned char *evbin;
+    int *hist, *vars;
+    uint32_t *lc; int lcn;
+};
+constexpr uint32_t kNoClaim = 0xffffffffu;
+__host__ __device__ inline size_t init_state_bytes(size_t n, size_t nq, size_t lcn)
+{
+    n = (n + 3) & ~(size_t)3; nq = (nq + 3) & ~(size_t)3;
+    return nq * 4 + nq * 4 + n * 4 + 2 * nq * 4 + 2 * n * 4 + 2 * nq * 2 + nq + (HISTO_LENGTH + 2 + 16) * 4 + (lcn ? nq * (lcn + 1) * 4 : 0);
+}
+__global__ __launch_bounds__(1024) void k_resolve_init(DevFrame F, const orbhip_keypoint *__restrict__ qkeys, int nq,
+                                                       const unsigned long long *__restrict__ cand,
+                                                       const unsigned long long *__restrict__ ccand,
+                                                       const int *__restrict__ cnt, int stride, float nnratio, int check_ori,
+                                                       int *__restrict__ out, int *__restrict__ out_n, Batch B, int n_alloc,
+                                                       int nq_alloc, int lcn)
+{
+    extern __shared__ unsigned char resolve_lds[];
+    const int tid = threadIdx.x, T = blockDim.x;
+    if (B.qcap > 0) {   // batched (device-resident) call: one workgroup per pair
+        const int pair = blockIdx.x;
+        batch_frame(F, B, pair);
+        if (qkeys) qkeys += (size_t)(B.qd0 + pair * B.qds) * B.qcap;
+        cand += (size_t)pair * B.qcap * stride;
+        ccand += (size_t)pair * B.qcap * kCompact;
+        cnt += (size_t)pair * B.qcap;
+        out += (size_t)pair * B.qcap;
+        out_n += pair;
+        if (B.nq_dev) nq = min(B.nq_dev[pair], B.qcap);
+    }
+    const int n = F.n;
+    InitState S;
+    {
+        const size_t na = ((size_t)n_alloc + 3) & ~(size_t)3, nqa = ((size_t)nq_alloc + 3) & ~(size_t)3;
+        int *p = reinterpret_cast<int *>(resolve_lds);
+        S.q_cnt = p; p += nqa;
+        S.q_angle = reinterpret_cast<float *>(p); p += nqa;
+        S.t_angle = reinterpret_cast<float *>(p); p += na;
+        S.claim[0] = reinterpret_cast<uint32_t *>(p); p += nqa; S.claim[1] = reinterpret_cast<uint32_t *>(p); p += nqa;
+        S.head[0] = p; p += na; S.head[1] = p; p += na;
+        S.hist = p; p += HISTO_LENGTH + 2; S.vars = p; p += 16;
+        S.next[0] = reinterpret_cast<unsigned short *>(p); S.next[1] = S.next[0] + nqa; p += nqa;
+        S.evbin = reinterpret_cast<unsigned char *>(p); p += nqa / 4;
+        S.lc = reinterpret_cast<uint32_t *>(p); S.lcn = lcn;
+    }
+    // list heads of this thread's first query, requested before anything else (one memory round trip with the rest)
+    unsigned long long hv[kResolveHead];
+    int head_c = 0;
+    if (tid < nq) {
+        head_c = cnt[tid];
+        if (S.lcn > 0) {
+            const unsigned long long *l0 = ccand + (size_t)tid * kCompact;
+#pragma unroll
+            for (int e = 0; e < kResolveHead; ++e) hv[e] = l0[e];
+        }
+    }
+    for (int i = tid; i < n; i += T) { S.t_angle[i] = F.keys[i].angle; S.head[0][i] = -1; }
+    for (int i = tid; i < nq; i += T) {
+        S.q_cnt[i] = i == tid ? head_c : cnt[i];
+        S.q_angle[i] = qkeys[i].angle;
+        S.claim[0][i] = kNoClaim;
+        S.next[0][i] = 0xffff;
+        S.evbin[i] = 0xff;
+    }
+    if (tid < HISTO_LENGTH) S.hist[tid] = 0;
+    if (tid < 16) S.vars[tid] = 0;
+    if (S.lcn > 0) {
+        for (int i = tid; i < nq; i += T) {
+            const int c = i == tid ? head_c : cnt[i];
+            if (c <= 0) continue;
+            if (i != tid) {
+                const unsigned long long *l0 = ccand + (size_t)i * kCompact;
+#pragma unroll
+                for (int e = 0; e < kResolveHead; ++e) hv[e] = (e < c && e < S.lcn) ? l0[e] : ~0ull;
+            }
+#pragma unroll
+            for (int e = 0; e < kResolveHead; ++e)
+                if (e < c && e < S.lcn) S.lc[i * (S.lcn + 1) + e] = ((uint32_t)(hv[e] >> 32) << 20) | (uint32_t)(hv[e] & 0xfffffu);
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    // vars[0..2]: "a claim changed" flags in rotation (raised in a round, reset one round ahead)
+    int f_cur = 0, f_nxt = 1;
+    for (int round = 0; round <= nq + 1; ++round) {
+        const int nxt = cur ^ 1;
+        const uint32_t *claim_c = S.claim[cur];
+        const int *head_c2 = S.head[cur];
+        const unsigned short *next_c = S.next[cur];
+        uint32_t *claim_n = S.claim[nxt];
+        int *head_n = S.head[nxt];
+        unsigned short *next_n = S.next[nxt];
+        for (int b = tid; b < n; b += T) head_n[b] = -1;
+        if (tid == 0) S.vars[f_nxt] = 0;
+        __syncthreads();
+        bool ch = false;
+        for (int i = tid; i < nq; i += T) {
+            const int c = S.q_cnt[i];
+            uint32_t k1 = kNoClaim;
+            int d2 = INT_MAX;
+            // the smallest distance an accepted query with a smaller index has left on slot b (vMatchedDistance)
+            auto left_on = [&](int b) -> int {
+                int D = INT_MAX;
+                for (int j = head_c2[b]; j >= 0; j = next_c[j] == 0xffff ? -1 : (int)next_c[j])
+                    if (j < i) D = min(D, (int)(claim_c[j] >> 20));
+                return D;
+            };
+            if (c > 0) {          // sorted by (distance, visiting order): first and second usable entry
+                const unsigned long long *list = ccand + (size_t)i * kCompact;
+                const uint32_t *lrow = S.lc + i * (S.lcn + 1);
+                for (int e = 0; e < c; ++e) {
+                    uint32_t w;
+                    if (e < S.lcn) w = lrow[e];
+                    else { const unsigned long long v = list[e]; w = ((uint32_t)(v >> 32) << 20) | (uint32_t)(v & 0xfffffu); }
+                    const int d = (int)(w >> 20), b = (int)(w & 0xfffffu);
+                    if (left_on(b) <= d) continue;
+                    if (k1 == kNoClaim) k1 = w; else { d2 = d; break; }
+                }
+            } else if (c < 0) {   // more than 64 candidates, unsorted: smallest and second smallest usable key
+                const unsigned long long *list = cand + (size_t)i * stride;
+                unsigned long long m1 = ~0ull, m2 = ~0ull;
+                for (int e = 0; e < -c; ++e) {
+                    const unsigned long long v = list[e];
+                    if (left_on((int)(v & 0xfffffu)) <= (int)(v >> 32)) continue;
+                    if (v < m1) { m2 = m1; m1 = v; } else if (v < m2) m2 = v;
+                }
+                if (m1 != ~0ull) k1 = ((uint32_t)(m1 >> 32) << 20) | (uint32_t)(m1 & 0xfffffu);
+                if (m2 != ~0ull) d2 = (int)(m2 >> 32);
+            }
+            uint32_t mine = kNoClaim;
+            if (k1 != kNoClaim) {
+                const int d1 = (int)(k1 >> 20);
+                // bestDist <= TH_LOW && bestDist < (float)bestDist2 * mfNNratio, bestDist2 = INT_MAX when absent
+                if (d1 <= TH_LOW && (float)d1 < __fmul_rn((float)d2, nnratio)) mine = k1;
+            }
+            claim_n[i] = mine;
+            if (mine != kNoClaim) {
+                const int old = atomicExch(&head_n[(int)(mine & 0xfffffu)], i);
+                next_n[i] = old < 0 ? (unsigned short)0xffff : (unsigned short)old;
+            }
+            ch |= mine != claim_c[i];
+        }
+        if (ch) S.vars[f_cur] = 1;
+        __syncthreads();
+        const int changed = S.vars[f_cur];
+        cur = nxt;
+        { const int t_ = f_cur; f_cur = f_nxt; f_nxt = 3 - t_ - f_nxt; }
+        if (!changed) break;
+    }
+    // ---- outcome: a claim holds its slot unless a later query claimed the same slot (it was closer: it stole it);
+    // every accepted query enters the rotation histogram, stolen or not, as the reference's rotHist does ----
+    const uint32_t *claim = S.claim[cur];
+    const int *head = S.head[cur];
+    const unsigned short *next = S.next[cur];
+    int kept = 0;
+    for (int i0 = 0; i0 < nq; i0 += T) {
+        const int i = i0 + tid;
+        int m = -1, bin = -1;
+        if (i < nq && claim[i] != kNoClaim) {
+            const int b = (int)(claim[i] & 0xfffffu);
+            bool stolen = false;
+            for (int j = head[b]; j >= 0; j = next[j] == 0xffff ? -1 : (int)next[j]) stolen |= j > i;
+            if (!stolen) m = b;
+            if (check_ori) {
+                bin = rot_bin(S.q_angle[i], S.t_angle[b]);
+                if (bin >= 0) S.evbin[i] = (unsigned char)bin;
+            }
+        }
+        if (i < nq) { S.q_cnt[i] = m; kept += m >= 0; }   // q_cnt is free now: vnMatches12
+        unsigned long long todo = __ballot(bin >= 0);
+        while (todo) {
+            const int first = __ffsll((long long)todo) - 1;
+            const int lead = __builtin_amdgcn_readlane(bin, first);
+            const unsigned long long same = __ballot(bin == lead);
+            if ((tid & 63) == first) atomicAdd(&S.hist[lead], __popcll(same));
+            todo &= ~same;
+        }
+    }
+    kept = wave_reduce_add_i(kept);
+    if ((tid & 63) == 0 && kept) atomicAdd(&S.vars[4], kept);
+    __syncthreads();
+    if (check_ori) {
+        if (tid < 64) {
+            int i1, i2, i3;
+            three_maxima(S.hist, i1, i2, i3);
+            if (tid == 0) { S.vars[8] = i1; S.vars[9] = i2; S.vars[10] = i3; }
+        }
+        __syncthreads();
+        const int ind1 = S.vars[8], ind2 = S.vars[9], ind3 = S.vars[10];
+        int cull = 0;
+        for (int i = tid; i < nq; i += T) {
+            const int b = S.evbin[i];
+            if (b != 0xff && b != ind1 && b != ind2 && b != ind3 && S.q_cnt[i] >= 0) { S.q_cnt[i] = -1; ++cull; }
+        }
+        cull = wave_reduce_add_i(cull);
+        if ((tid & 63) == 0 && cull) atomicAdd(&S.vars[5], cull);
+        __syncthreads();
+    }
+    for (int i = tid; i < nq; i += T) out[i] = S.q_cnt[i];
+    if (tid == 0) *out_n = S.vars[4] - S.vars[5];
+}
+
 // ---- DescriptorDistance, batched (ORBmatcher.cc:1647-1663) --------------------------------
 __global__ void k_distance_matrix(const uint8_t *__restrict__ a, int na, const uint8_t *__restrict__ b, int nb,
                                   int *__restrict__ dist)
@@ -2017,9 +2235,29 @@ static int ensure_resolve_attr(orbhip_matcher *m)
                                              (int)sizeof(ResolveShared)));
         ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_par<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              kResolveLdsBudget));
+        ORBHIP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resolve_init), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             kResolveLdsBudget));
         m->lds_attr_set = true;
     }
     return ORBHIP_OK;
+}
+
+// SearchForInitialization's resolve: the parallel kernel while its state fits the LDS budget (always, within the
+// 4096-keypoint limit of the entry points), the serial replay otherwise
+static void launch_resolve_init(orbhip_matcher *m, int pairs, const DevFrame &D, const orbhip_keypoint *d_qkeys, const orbhip_query *d_q,
+                                int nq, int n_train, const unsigned long long *d_cand, const unsigned long long *d_ccand,
+                                const int *d_cnt, int stride, float nnratio, int check_ori, int *d_out, int *d_out_n, const Batch &B)
+{
+    static const bool dev_serial = getenv("ORBHIP_INIT_SERIAL") != nullptr;   // development switch: the serial replay
+    const size_t bare = init_state_bytes((size_t)n_train, (size_t)nq, 0);
+    if (!dev_serial && n_train <= kResolveMax && nq <= kResolveMax && bare <= (size_t)kResolveLdsBudget) {
+        const int lcn = init_state_bytes((size_t)n_train, (size_t)nq, kResolveHead) <= (size_t)kResolveLdsBudget ? kResolveHead : 0;
+        hipLaunchKernelGGL(k_resolve_init, dim3(pairs), dim3(1024), init_state_bytes((size_t)n_train, (size_t)nq, (size_t)lcn), m->stream,
+                           D, d_qkeys, nq, d_cand, d_ccand, d_cnt, stride, nnratio, check_ori, d_out, d_out_n, B, n_train, nq, lcn);
+    } else {
+        hipLaunchKernelGGL(k_resolve, dim3(pairs), dim3(64), sizeof(ResolveShared), m->stream, 2, D, d_qkeys, d_q, nq, d_cand, d_ccand,
+                           d_cnt, stride, (const uint8_t *)nullptr, nnratio, check_ori, d_out, d_out_n, B);
+    }
 }
 
 // launch of the parallel resolve: LDS state up to kResolveMax train keypoints / queries, HBM state beyond
@@ -2152,9 +2390,8 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
     if ((rc = launch_window_search(m, 1, D, train->n, d_q, d_qdesc, nqv, d_cand, d_cnt, stride, mode != 2 && use_ur, one, &d_ccand)))
         return rc;
     if ((rc = ensure_resolve_attr(m))) return rc;
-    if (mode == 2)   // SearchForInitialization: match stealing depends on the running minimum distance -> serial replay
-        hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), sizeof(ResolveShared), m->stream, mode, D, d_qkeys, d_q, nq, d_cand,
-                           d_ccand, d_cnt, stride, d_taken, nnratio, check_ori, d_out, d_out + nout, one);
+    if (mode == 2)   // SearchForInitialization: match stealing depends on the running minimum distance per slot
+        launch_resolve_init(m, 1, D, d_qkeys, d_q, nq, train->n, d_cand, d_ccand, d_cnt, stride, nnratio, check_ori, d_out, d_out + nout, one);
     else if ((rc = launch_resolve_par(m, 1, mode, D, d_q, nqv, train->n, d_cand, d_ccand, d_cnt, stride, d_taken, nnratio, check_ori,
                                       d_out, d_out + nout, one, th_accept, all_block)))
         return rc;
@@ -2893,8 +3130,8 @@ int orbhip_search_for_initialization_device(orbhip_matcher *m, int pairs, const 
     const Batch B = {(const int *)d_n, d_nq, cap, cap, f2_first, f2_step, f1_first, f1_step};
     unsigned long long *d_ccand;
     if ((rc = launch_window_search(m, pairs, D, cap, d_q, (const uint8_t *)d_desc, cap, d_cand, d_cnt, stride, 0, B, &d_ccand))) return rc;
-    hipLaunchKernelGGL(k_resolve, dim3(pairs), dim3(64), sizeof(ResolveShared), m->stream, 2, D, keys, d_q, cap, d_cand, d_ccand, d_cnt,
-                       stride, (const uint8_t *)nullptr, nnratio, check_ori, (int *)d_matches12, (int *)d_nmatches, B);
+    launch_resolve_init(m, pairs, D, keys, d_q, cap, cap, d_cand, d_ccand, d_cnt, stride, nnratio, check_ori, (int *)d_matches12,
+                        (int *)d_nmatches, B);
     hipLaunchKernelGGL(k_init_update_prev, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, keys, cap, f2_first, f2_step,
                        d_nq, (const int *)d_matches12, (float *)d_prev_matched);
     ORBHIP_HIP_CHECK(hipGetLastError());
