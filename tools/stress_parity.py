@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU: ORBextractor (stage by stage) and the two SearchByProjection searches against the
 oracle on random image sizes, feature counts, scale factors, level counts, thresholds, shifts, `taken` / `observed`
-patterns, and Frame::ComputeStereoMatches on every third case.  Complements the fixed-seed suite in tests/ (which covers every entry point); this one hunts for rare
+patterns, SearchForInitialization with random windows, and Frame::ComputeStereoMatches on every third case.  Complements the fixed-seed suite in tests/ (which covers every entry point); this one hunts for rare
 geometry- or data-dependent mismatches.  Exit code 1 on the first mismatch (the failing case is printed).
 
   python tools/stress_parity.py [--cases 60] [--seed 1]
@@ -93,6 +93,21 @@ def main():
         n2, assign2 = m2.SearchByProjectionPoints(gv, q2, d0, taken)
         on2, oassign2 = O.search_by_projection_points(ov, q2, d0, taken, nnr)
         assert n2 == on2 and np.array_equal(assign2, oassign2), desc + " SearchByProjection(points)"
+        ni = -1
+        if len(k0) <= 4096 and len(k1) <= 4096:
+            # SearchForInitialization(F1, F2, vbPrevMatched, windowSize) with random window / ratio / perturbed start points
+            keep1 = []
+            g1 = pkg.FrameView(k0, d0, sf, frame_bounds(img0))
+            o1 = O.make_frame(k0, d0, None, frame_bounds(img0), sf, keep1)
+            prev = np.stack([k0["x"], k0["y"]], 1).astype(np.float32) + rng.normal(0, 2.0, (len(k0), 2)).astype(np.float32)
+            win = int(rng.choice([20, 50, 100, 160])); nni = float(rng.choice([0.6, 0.9])); ori_i = bool(rng.random() < 0.7)
+            mi = pkg.ORBmatcher(nni, ori_i)
+            gv0 = pkg.FrameView(k1, d1, sf, b)
+            keep2 = []
+            ov0 = O.make_frame(k1, d1, None, b, sf, keep2)
+            ni, m12, pm = mi.SearchForInitialization(g1, gv0, prev, win)
+            oni, om12, opm = O.search_for_initialization(o1, ov0, prev, win, nni, ori_i)
+            assert ni == oni and np.array_equal(m12, om12) and np.array_equal(pm, opm), desc + " SearchForInitialization(window %d)" % win
         ns = -1
         if case % 3 == 0 and W >= 400 and H >= 200:
             # Frame::ComputeStereoMatches on a synthetic rectified pair of the same size and extractor parameters
@@ -111,7 +126,7 @@ def main():
                 t = oL.tables()
                 on3, our, odp = O.compute_stereo_matches(okl, odl, okr, odr, lv_l, lv_r, t["scale"], t["inv_scale"], float(mbf), float(mb))
                 assert ns == on3 and np.array_equal(urr, our) and np.array_equal(dpp, odp), desc + " ComputeStereoMatches"
-        print("%s -> ok (%d / %d keypoints, %d / %d matches, stereo %d) [%.0f s]" % (desc, len(k0), len(k1), n, n2, ns, time.time() - t0), flush=True)
+        print("%s -> ok (%d / %d keypoints, %d / %d matches, init %d, stereo %d) [%.0f s]" % (desc, len(k0), len(k1), n, n2, ni, ns, time.time() - t0), flush=True)
     print("stress parity: all cases passed")
     return 0
 
