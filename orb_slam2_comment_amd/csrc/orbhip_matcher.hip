@@ -1941,6 +1941,13 @@ struct StereoGeom {
     float mbf, mb;
 };
 
+// rows a right keypoint's band can reach from floor(y): ceil(2 * largest scale factor) + 1
+static int stereo_row_reach(const StereoGeom &G)
+{
+    float mx = 0.f;
+    for (int l = 0; l < G.nlevels; ++l) mx = std::max(mx, G.sf[l]);
+    return (int)ceilf(2.0f * mx) + 1;
+}
 // Batched stereo: pair p uses frame l0 + p*ls of the left arrays/pyramids and r0 + p*rs of the right ones.
 struct StereoBatch {
     const int *n_l, *n_r;   // per-frame keypoint counts on the device, or null (use the nl / nr arguments)
@@ -1949,26 +1956,46 @@ struct StereoBatch {
     unsigned fb_l, fb_r;    // pyramid bytes per frame of the two extractor handles
 };
 
-// row band of every right keypoint (Frame.cc:483-493)
-__global__ void k_stereo_rows(const orbhip_keypoint *__restrict__ kr, int nr, StereoGeom G, int2 *__restrict__ band,
-                              StereoBatch B)
+// Right keypoints bucketed by image row (counting sort on floor(y)): a left keypoint's candidates -- the right keypoints
+// whose row band [floor(y - r), ceil(y + r)], r = 2 * scale[octave] (Frame.cc:483-493) contains its row -- all lie within
+// R = ceil(2 * largest scale) + 1 rows of it, i.e. in ONE contiguous range of the sorted order, instead of anywhere among
+// the nr right keypoints.  One workgroup per pair; rowstart[nrows + 1], order[nr] (order inside a row is irrelevant: the
+// match is the minimum of (distance, index) keys).
+constexpr int kStereoRowsMax = 4096;
+__global__ __launch_bounds__(256) void k_stereo_sort(const orbhip_keypoint *__restrict__ kr, int nr, int nrows,
+                                                     int *__restrict__ rowstart, int *__restrict__ order, StereoBatch B)
 {
-    const int pair = blockIdx.y, fr = B.r0 + pair * B.rs;
+    __shared__ int s_cnt[kStereoRowsMax];
+    __shared__ int s_wave[4];
+    const int tid = threadIdx.x, pair = blockIdx.x, fr = B.r0 + pair * B.rs;
     kr += (size_t)fr * B.cap;
-    band += (size_t)pair * B.cap;
+    rowstart += (size_t)pair * (nrows + 1);
+    order += (size_t)pair * B.cap;
     if (B.n_r) nr = min(B.n_r[fr], B.cap);
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nr) return;
-    const float kpY = kr[i].y;
-    const float r = __fmul_rn(2.0f, G.sf[kr[i].octave]);
-    band[i] = make_int2((int)floorf(__fsub_rn(kpY, r)), (int)ceilf(__fadd_rn(kpY, r)));
+    for (int r = tid; r < nrows; r += 256) s_cnt[r] = 0;
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) atomicAdd(&s_cnt[min(max((int)floorf(kr[i].y), 0), nrows - 1)], 1);
+    __syncthreads();
+    const int per = (nrows + 255) / 256, r0 = tid * per, r1 = min(r0 + per, nrows);
+    int sum = 0;
+    for (int r = r0; r < r1; ++r) sum += s_cnt[r];
+    const int incl = wave_incl_scan_add(sum);
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < (tid >> 6); ++w) base += s_wave[w];
+    for (int r = r0; r < r1; ++r) { const int c = s_cnt[r]; s_cnt[r] = base; rowstart[r] = base; base += c; }
+    if (tid == 255) rowstart[nrows] = base;
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) order[atomicAdd(&s_cnt[min(max((int)floorf(kr[i].y), 0), nrows - 1)], 1)] = i;
 }
 
 __global__ __launch_bounds__(256) void k_stereo_match(const orbhip_keypoint *__restrict__ kl,
                                                       const uint8_t *__restrict__ dl, int nl,
                                                       const orbhip_keypoint *__restrict__ kr,
                                                       const uint8_t *__restrict__ dr, int nr,
-                                                      const int2 *__restrict__ band, StereoGeom G,
+                                                      const int *__restrict__ rowstart, const int *__restrict__ order, int R,
+                                                      StereoGeom G,
                                                       float *__restrict__ uRight, float *__restrict__ depth,
                                                       int *__restrict__ sad, StereoBatch B)
 {
@@ -1979,7 +2006,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbhip_keypoint *__r
         pyr_off_l = (size_t)fl * B.fb_l; pyr_off_r = (size_t)fr * B.fb_r;
         kl += (size_t)fl * B.cap; dl += (size_t)fl * B.cap * 32;
         kr += (size_t)fr * B.cap; dr += (size_t)fr * B.cap * 32;
-        band += (size_t)pair * B.cap;
+        if (rowstart) { rowstart += (size_t)pair * (G.nrows + 1); order += (size_t)pair * B.cap; }
         uRight += (size_t)pair * B.cap; depth += (size_t)pair * B.cap; sad += (size_t)pair * B.cap;
         if (B.n_l) nl = min(B.n_l[fl], B.cap);
         if (B.n_r) nr = min(B.n_r[fr], B.cap);
@@ -2002,14 +2029,22 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbhip_keypoint *__r
     const uint32_t *qp = reinterpret_cast<const uint32_t *>(dl + (size_t)iL * 32);
 #pragma unroll
     for (int i = 0; i < 8; ++i) qd[i] = qp[i];
-    // best right keypoint on this row: smallest (dist, iR) with dist < TH_HIGH (:522-549)
+    // best right keypoint on this row: smallest (dist, iR) with dist < TH_HIGH (:522-549).  Candidates: the rows within R
+    // of this one in the row-sorted order (all right keypoints when there is no order)
     unsigned long long best = ((unsigned long long)TH_HIGH << 32);
-    for (int j0 = 0; j0 < nr; j0 += 64) {
-        const int iR = j0 + lane;
-        if (iR < nr) {
-            const int2 bd = band[iR];
+    int jb = 0, je = nr;
+    if (rowstart) { jb = rowstart[max(row - R, 0)]; je = rowstart[min(row + R + 1, G.nrows)]; }
+    for (int j0 = jb; j0 < je; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < je) {
+            const int iR = rowstart ? order[j] : j;
             const orbhip_keypoint kpR = kr[iR];
-            if (row >= bd.x && row <= bd.y && !(kpR.octave < levelL - 1 || kpR.octave > levelL + 1) &&
+            float sfo = G.sf[0];   // scale of the right keypoint's level, by selects (a lane-indexed read would put G into scratch)
+#pragma unroll
+            for (int l = 1; l < ORBHIP_MAX_LEVELS; ++l) sfo = kpR.octave == l ? G.sf[l] : sfo;
+            const float r = __fmul_rn(2.0f, sfo);
+            const int minr = (int)floorf(__fsub_rn(kpR.y, r)), maxr = (int)ceilf(__fadd_rn(kpR.y, r));
+            if (row >= minr && row <= maxr && !(kpR.octave < levelL - 1 || kpR.octave > levelL + 1) &&
                 kpR.x >= minU && kpR.x <= maxU) {
                 const uint32_t *tp = reinterpret_cast<const uint32_t *>(dr + (size_t)iR * 32);
                 uint32_t td[8];
@@ -3080,16 +3115,19 @@ int orbhip_compute_stereo_matches_device(orbhip_matcher *m, orbhip_extractor *le
     for (int l = G.nlevels; l < ORBHIP_MAX_LEVELS; ++l) { G.left[l] = G.left[0]; G.right[l] = G.right[0]; }
     void *p;
     int rc;
-    if ((rc = scratch(m, S_ORD, (size_t)pairs * cap * sizeof(int2), &p))) return rc;
-    int2 *d_band = (int2 *)p;
+    if ((rc = scratch(m, S_ORD, (size_t)pairs * ((size_t)G.nrows + 1 + cap) * sizeof(int), &p))) return rc;
+    int *d_rowstart = (int *)p, *d_order = d_rowstart + (size_t)pairs * (G.nrows + 1);
     if ((rc = scratch(m, S_CNT, (size_t)pairs * cap * sizeof(int), &p))) return rc;
     int *d_sad = (int *)p;
     const StereoBatch B = {(const int *)d_n_l, (const int *)d_n_r, l0, ls, r0, rs, cap, left->G.frame_bytes, right->G.frame_bytes};
-    hipLaunchKernelGGL(k_stereo_rows, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, (const orbhip_keypoint *)d_kps_r,
-                       cap, G, d_band, B);
+    const int R = stereo_row_reach(G);
+    if (G.nrows <= kStereoRowsMax)
+        hipLaunchKernelGGL(k_stereo_sort, dim3(pairs), dim3(256), 0, m->stream, (const orbhip_keypoint *)d_kps_r, cap, G.nrows, d_rowstart,
+                           d_order, B);
+    else d_rowstart = nullptr;   // taller images: every right keypoint is a candidate
     hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, pairs), dim3(256), 0, m->stream, (const orbhip_keypoint *)d_kps_l,
-                       (const uint8_t *)d_desc_l, cap, (const orbhip_keypoint *)d_kps_r, (const uint8_t *)d_desc_r, cap, d_band,
-                       G, (float *)d_u_right, (float *)d_depth, d_sad, B);
+                       (const uint8_t *)d_desc_l, cap, (const orbhip_keypoint *)d_kps_r, (const uint8_t *)d_desc_r, cap,
+                       (const int *)d_rowstart, (const int *)d_order, R, G, (float *)d_u_right, (float *)d_depth, d_sad, B);
     hipLaunchKernelGGL(k_stereo_cull, dim3(pairs), dim3(256), 0, m->stream, cap, d_sad, (float *)d_u_right, (float *)d_depth,
                        (int *)d_nmatches, B);
     ORBHIP_HIP_CHECK(hipGetLastError());
@@ -3393,8 +3431,8 @@ int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int
     const orbhip_keypoint *d_kr = (const orbhip_keypoint *)st.put(keys_r, (size_t)nr * sizeof(orbhip_keypoint));
     const uint8_t *d_dr = (const uint8_t *)st.put(desc_r, (size_t)nr * 32);
     if ((rc = stage_commit(m, &st))) return rc;
-    if ((rc = scratch(m, S_ORD, (size_t)nr * sizeof(int2), &p))) return rc;
-    int2 *d_band = (int2 *)p;
+    if ((rc = scratch(m, S_ORD, ((size_t)G.nrows + 1 + nr) * sizeof(int), &p))) return rc;
+    int *d_rowstart = (int *)p, *d_order = d_rowstart + (G.nrows + 1);
     // outputs contiguous: u_right[nl] | depth[nl] | sad[nl] | n
     if ((rc = scratch(m, S_OUT, (size_t)(3 * nl + 1) * sizeof(float), &p))) return rc;
     float *d_ur = (float *)p, *d_depth = d_ur + nl;
@@ -3402,9 +3440,11 @@ int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int
     uint8_t *h_out;
     if ((rc = out_buffer(m, (size_t)(3 * nl + 1) * sizeof(float), &h_out))) return rc;
     const StereoBatch one = {nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
-    hipLaunchKernelGGL(k_stereo_rows, dim3((nr + 255) / 256), dim3(256), 0, m->stream, d_kr, nr, G, d_band, one);
-    hipLaunchKernelGGL(k_stereo_match, dim3((nl + 3) / 4), dim3(256), 0, m->stream, d_kl, d_dl, nl, d_kr, d_dr, nr, d_band,
-                       G, d_ur, d_depth, d_sad, one);
+    if (G.nrows <= kStereoRowsMax)
+        hipLaunchKernelGGL(k_stereo_sort, dim3(1), dim3(256), 0, m->stream, d_kr, nr, G.nrows, d_rowstart, d_order, one);
+    else d_rowstart = nullptr;
+    hipLaunchKernelGGL(k_stereo_match, dim3((nl + 3) / 4), dim3(256), 0, m->stream, d_kl, d_dl, nl, d_kr, d_dr, nr,
+                       (const int *)d_rowstart, (const int *)d_order, stereo_row_reach(G), G, d_ur, d_depth, d_sad, one);
     hipLaunchKernelGGL(k_stereo_cull, dim3(1), dim3(256), 0, m->stream, nl, d_sad, d_ur, d_depth, d_n, one);
     ORBHIP_HIP_CHECK(hipGetLastError());
     ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_ur, (size_t)(3 * nl + 1) * sizeof(float), hipMemcpyDeviceToHost, m->stream));
