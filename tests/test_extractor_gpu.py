@@ -294,6 +294,40 @@ def test_batch_with_frame_and_row_strides(mods):
         assert np.array_equal(desc[b, :n[b]], od)
 
 
+def test_device_entry_with_row_and_frame_strides(mods):
+    """orbhip_extract_batch_device on frames that are ROIs of a larger DEVICE buffer: row stride > cols and an odd byte
+    offset -- the pyramid kernels read the input image itself (level 0 and level 1), not a compacted copy."""
+    import torch
+    pkg, O = mods
+    B, H, W, SH, SW = 3, 240, 321, 262, 357
+    big = np.zeros((B, SH, SW), np.uint8)
+    frames = [synth_frame(50 + b, W, H) for b in range(B)]
+    for b in range(B):
+        big[b, 11:11 + H, 17:17 + W] = frames[b]
+    dev = torch.device("cuda", 0)
+    d_big = torch.from_numpy(big).to(dev)
+    ext = pkg.ORBextractor(400, 1.2, 6, 20, 7)
+    cap = ext.capacity(H, W)
+    d_k = torch.zeros((B, cap, 7), dtype=torch.int32, device=dev)
+    d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_s = torch.zeros(B, dtype=torch.int32, device=dev)
+    ext.extract_batch_device(d_big.data_ptr() + 11 * SW + 17, B, H, W, d_k.data_ptr(), d_d.data_ptr(), cap, d_n.data_ptr(),
+                             d_s.data_ptr(), stride=SW, frame_stride=SH * SW)
+    ext.sync()
+    n = d_n.cpu().numpy()
+    assert int(d_s.abs().sum().item()) == 0
+    kps = d_k.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, cap)
+    desc = d_d.cpu().numpy()
+    ora = O.OracleExtractor(400, 1.2, 6, 20, 7)
+    for b in range(B):
+        ok, od = ora.extract(frames[b])
+        assert_kps_equal(kps[b, :n[b]], ok, "frame %d" % b)
+        assert np.array_equal(desc[b, :n[b]], od)
+        assert np.array_equal(ext.image_pyramid(0, with_border=True, frame=b), ora.level_padded(0))
+        assert np.array_equal(ext.image_pyramid(1, with_border=True, frame=b), ora.level_padded(1))
+
+
 def test_host_api_graph_replay_is_invalidated_correctly(mods):
     """The host-pointer entry replays a captured hipGraph; every event that changes a captured argument must drop it:
     batch size, capacity (new geometry), image size, blur weights, stream.  Results must not depend on the history."""
