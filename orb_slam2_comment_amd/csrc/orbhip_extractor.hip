@@ -1988,6 +1988,13 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
     return ORBHIP_OK;
 }
 
+// development switch: blur kernel + unfused orientation / descriptor kernel (the round-1 structure)
+static bool dev_separate_blur()
+{
+    static const bool on = getenv("ORBHIP_SEPARATE_BLUR") != nullptr;
+    return on;
+}
+
 static int ensure_batch(orbhip_extractor *e, int batch)
 {
     if (batch <= e->batch_cap) return ORBHIP_OK;
@@ -1996,6 +2003,7 @@ static int ensure_batch(orbhip_extractor *e, int batch)
     const PyrGeom &G = e->G;
     const size_t B = (size_t)batch;
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_pyr, B * G.frame_bytes));
+    if (dev_separate_blur()) ORBHIP_HIP_CHECK(hipMalloc(&e->d_blur, B * G.frame_bytes));   // otherwise allocated when a blurred plane is asked for
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_cell_cnt, B * std::max(G.ncells_total, 1) * sizeof(int)));
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_cell_kp, B * std::max(G.ncells_total, 1) * G.slot_cap * sizeof(uint32_t)));
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_keys, B * G.cand_cap_total * sizeof(uint32_t)));
@@ -2016,8 +2024,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     const PyrGeom &G = e->G;
     hipStream_t s = e->stream;
     // per-frame internal buffers of this launch
-    static const bool dev_sep = getenv("ORBHIP_SEPARATE_BLUR") != nullptr;   // development switch: blur kernel + unfused describe
-    if (dev_sep && !e->d_blur) ORBHIP_HIP_CHECK(hipMalloc(&e->d_blur, (size_t)e->batch_cap * G.frame_bytes));
+    const bool dev_sep = dev_separate_blur();
     uint8_t *const b_pyr = e->d_pyr + (size_t)frame0 * G.frame_bytes, *const b_blur = e->d_blur ? e->d_blur + (size_t)frame0 * G.frame_bytes : nullptr;
     int *const b_cell_cnt = e->d_cell_cnt + (size_t)frame0 * std::max(G.ncells_total, 1);
     uint32_t *const b_cell_kp = e->d_cell_kp + (size_t)frame0 * std::max(G.ncells_total, 1) * G.slot_cap;
