@@ -180,7 +180,7 @@ class OracleExtractor:
 
     def extract(self, img):
         img = np.ascontiguousarray(img, dtype=np.uint8)
-        cap = self.nfeatures + 3 * self.nlevels + 64
+        cap = 2 * self.nfeatures + 64 * self.nlevels + 256    # >= sum over levels of max(quota + 3, 4 * nIni)
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = self.L.oracle_extract(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0],

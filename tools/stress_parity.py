@@ -93,6 +93,15 @@ def main():
         n2, assign2 = m2.SearchByProjectionPoints(gv, q2, d0, taken)
         on2, oassign2 = O.search_by_projection_points(ov, q2, d0, taken, nnr)
         assert n2 == on2 and np.array_equal(assign2, oassign2), desc + " SearchByProjection(points)"
+        if case % 5 == 0:
+            # the batch entry on the same size: 5 frames in one call = the single-frame results
+            fr = np.stack([img0, img1, synth_frame(seed + 1, W, H), img0, synth_frame(seed + 2, W, H)])
+            res = ext.extract_batch(fr)
+            assert_kps_equal(res[0][0], ok0, desc + " batch frame 0"); assert np.array_equal(res[0][1], od0), desc
+            assert_kps_equal(res[1][0], ok1, desc + " batch frame 1"); assert np.array_equal(res[1][1], od1), desc
+            assert_kps_equal(res[3][0], ok0, desc + " batch frame 3"); assert np.array_equal(res[3][1], od0), desc
+            ok2, od2 = ora.extract(fr[2])
+            assert_kps_equal(res[2][0], ok2, desc + " batch frame 2"); assert np.array_equal(res[2][1], od2), desc
         ni = -1
         if len(k0) <= 4096 and len(k1) <= 4096:
             # SearchForInitialization(F1, F2, vbPrevMatched, windowSize) with random window / ratio / perturbed start points
