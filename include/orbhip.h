@@ -121,7 +121,9 @@ int orbhip_pyramid_level(orbhip_extractor *e, int frame, int level, int *rows, i
 /* Copy a level to host.  with_border != 0 copies the (rows+38)x(cols+38) padded plane. */
 int orbhip_pyramid_level_download(orbhip_extractor *e, int frame, int level, int with_border,
                                   uint8_t *dst, int dst_stride);
-/* Debug/parity taps of the last call (host copies). */
+/* Debug/parity taps of the last call (host copies).  The blurred planes are not part of the pipeline (only the
+ * keypoints' patches are blurred, inside the descriptor kernel): the first request after an extraction runs the
+ * 7x7 Gaussian blur over the whole pyramid of the last batch. */
 int orbhip_blurred_level_download(orbhip_extractor *e, int frame, int level, uint8_t *dst,
                                   int dst_stride);
 /* FAST candidates of a level in reference order: x,y (relative to minBorder), score. */
@@ -130,8 +132,9 @@ int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *
 
 /* Per-stage device time, microseconds, averaged over the extract calls made since
  * orbhip_extractor_set_profiling(e, 1) (at most the last 256), measured with HIP events on the
- * handle's stream: [0] pyramid (8 launches), [1] FAST+NMS cells, [2] octree, [3] blur,
- * [4] orientation+descriptors, [5] whole call. */
+ * handle's stream: [0] pyramid (7 launches), [1] FAST+NMS cells, [2] octree, [3] blur (no launch of its own any
+ * more: the descriptor kernel blurs the patches it samples, so this is the gap between two events), [4] blur of the
+ * patches + orientation + descriptors, [5] whole call. */
 int orbhip_extractor_set_profiling(orbhip_extractor *e, int on);
 int orbhip_extractor_stage_times(orbhip_extractor *e, float us[6]);
 
