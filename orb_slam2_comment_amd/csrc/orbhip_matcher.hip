@@ -1252,13 +1252,16 @@ struct InitState {
     unsigned short *next[2];     // per query: next claimant of the same slot, 0xffff = end
     unsigned char *evbin;
     int *hist, *vars;
+    unsigned short *active;      // queries with a sorted list (<= 64 candidates), in index order (SearchForInitialization
+                                 // only matches level-0 keypoints: about a fifth of the queries have candidates at all)
+    unsigned short *active_u;    // queries with more than 64 candidates (unsorted list): a whole wavefront steps each
     uint32_t *lc; int lcn;
 };
 constexpr uint32_t kNoClaim = 0xffffffffu;
 __host__ __device__ inline size_t init_state_bytes(size_t n, size_t nq, size_t lcn)
 {
     n = (n + 3) & ~(size_t)3; nq = (nq + 3) & ~(size_t)3;
-    return nq * 4 + nq * 4 + n * 4 + 2 * nq * 4 + 2 * n * 4 + 2 * nq * 2 + nq + (HISTO_LENGTH + 2 + 16) * 4 + (lcn ? nq * (lcn + 1) * 4 : 0);
+    return nq * 4 + nq * 4 + n * 4 + 2 * nq * 4 + 2 * n * 4 + 2 * nq * 2 + nq + 4 * nq + (HISTO_LENGTH + 2 + 64) * 4 + (lcn ? nq * (lcn + 1) * 4 : 0);
 }
 __global__ __launch_bounds__(1024) void k_resolve_init(DevFrame F, const orbhip_keypoint *__restrict__ qkeys, int nq,
                                                        const unsigned long long *__restrict__ cand,
@@ -1290,9 +1293,11 @@ __global__ __launch_bounds__(1024) void k_resolve_init(DevFrame F, const orbhip_
         S.t_angle = reinterpret_cast<float *>(p); p += na;
         S.claim[0] = reinterpret_cast<uint32_t *>(p); p += nqa; S.claim[1] = reinterpret_cast<uint32_t *>(p); p += nqa;
         S.head[0] = p; p += na; S.head[1] = p; p += na;
-        S.hist = p; p += HISTO_LENGTH + 2; S.vars = p; p += 16;
+        S.hist = p; p += HISTO_LENGTH + 2; S.vars = p; p += 64;
         S.next[0] = reinterpret_cast<unsigned short *>(p); S.next[1] = S.next[0] + nqa; p += nqa;
         S.evbin = reinterpret_cast<unsigned char *>(p); p += nqa / 4;
+        S.active = reinterpret_cast<unsigned short *>(p); p += nqa / 2;
+        S.active_u = reinterpret_cast<unsigned short *>(p); p += nqa / 2;
         S.lc = reinterpret_cast<uint32_t *>(p); S.lcn = lcn;
     }
     // list heads of this thread's first query, requested before anything else (one memory round trip with the rest)
@@ -1310,12 +1315,12 @@ __global__ __launch_bounds__(1024) void k_resolve_init(DevFrame F, const orbhip_
     for (int i = tid; i < nq; i += T) {
         S.q_cnt[i] = i == tid ? head_c : cnt[i];
         S.q_angle[i] = qkeys[i].angle;
-        S.claim[0][i] = kNoClaim;
+        S.claim[0][i] = kNoClaim; S.claim[1][i] = kNoClaim;
         S.next[0][i] = 0xffff;
         S.evbin[i] = 0xff;
     }
     if (tid < HISTO_LENGTH) S.hist[tid] = 0;
-    if (tid < 16) S.vars[tid] = 0;
+    if (tid < 64) S.vars[tid] = 0;
     if (S.lcn > 0) {
         for (int i = tid; i < nq; i += T) {
             const int c = i == tid ? head_c : cnt[i];
@@ -1331,6 +1336,29 @@ __global__ __launch_bounds__(1024) void k_resolve_init(DevFrame F, const orbhip_
         }
     }
     __syncthreads();
+    // compact the queries that have candidates (index order; sorted and unsorted lists separately): thread t owns
+    // queries [t * per, (t + 1) * per)
+    int nact, nact_u;
+    {
+        const int per = (nq + T - 1) / T, i_lo = tid * per, i_hi = min(i_lo + per, nq);
+        int c = 0, cu = 0;
+        for (int i = i_lo; i < i_hi; ++i) { c += S.q_cnt[i] > 0; cu += S.q_cnt[i] < 0; }
+        const int incl = wave_incl_scan_add(c), inclu = wave_incl_scan_add(cu);
+        if ((tid & 63) == 63) { S.vars[16 + (tid >> 6)] = incl; S.vars[32 + (tid >> 6)] = inclu; }
+        __syncthreads();
+        int base = incl - c, tot = 0, baseu = inclu - cu, totu = 0;
+        for (int w = 0; w < (T >> 6); ++w) {
+            const int v = S.vars[16 + w], vu = S.vars[32 + w];
+            if (w < (tid >> 6)) { base += v; baseu += vu; }
+            tot += v; totu += vu;
+        }
+        for (int i = i_lo; i < i_hi; ++i) {
+            if (S.q_cnt[i] > 0) S.active[base++] = (unsigned short)i;
+            else if (S.q_cnt[i] < 0) S.active_u[baseu++] = (unsigned short)i;
+        }
+        nact = tot; nact_u = totu;
+        __syncthreads();
+    }
     int cur = 0;
     // vars[0..2]: "a claim changed" flags in rotation (raised in a round, reset one round ahead)
     int f_cur = 0, f_nxt = 1;
@@ -1346,7 +1374,8 @@ __global__ __launch_bounds__(1024) void k_resolve_init(DevFrame F, const orbhip_
         if (tid == 0) S.vars[f_nxt] = 0;
         __syncthreads();
         bool ch = false;
-        for (int i = tid; i < nq; i += T) {
+        for (int a = tid; a < nact; a += T) {
+            const int i = S.active[a];
             const int c = S.q_cnt[i];
             uint32_t k1 = kNoClaim;
             int d2 = INT_MAX;
@@ -1368,16 +1397,6 @@ __global__ __launch_bounds__(1024) void k_resolve_init(DevFrame F, const orbhip_
                     if (left_on(b) <= d) continue;
                     if (k1 == kNoClaim) k1 = w; else { d2 = d; break; }
                 }
-            } else if (c < 0) {   // more than 64 candidates, unsorted: smallest and second smallest usable key
-                const unsigned long long *list = cand + (size_t)i * stride;
-                unsigned long long m1 = ~0ull, m2 = ~0ull;
-                for (int e = 0; e < -c; ++e) {
-                    const unsigned long long v = list[e];
-                    if (left_on((int)(v & 0xfffffu)) <= (int)(v >> 32)) continue;
-                    if (v < m1) { m2 = m1; m1 = v; } else if (v < m2) m2 = v;
-                }
-                if (m1 != ~0ull) k1 = ((uint32_t)(m1 >> 32) << 20) | (uint32_t)(m1 & 0xfffffu);
-                if (m2 != ~0ull) d2 = (int)(m2 >> 32);
             }
             uint32_t mine = kNoClaim;
             if (k1 != kNoClaim) {
@@ -1391,6 +1410,44 @@ __global__ __launch_bounds__(1024) void k_resolve_init(DevFrame F, const orbhip_
                 next_n[i] = old < 0 ? (unsigned short)0xffff : (unsigned short)old;
             }
             ch |= mine != claim_c[i];
+        }
+        // queries with more than 64 candidates (unsorted lists in HBM): one wavefront per query, lanes over the
+        // candidates, two wave minima = smallest and second smallest usable key
+        for (int u = tid >> 6; u < nact_u; u += T >> 6) {
+            const int i = S.active_u[u];
+            const int c = -S.q_cnt[i];
+            const unsigned long long *list = cand + (size_t)i * stride;
+            auto left_on = [&](int b) -> int {
+                int D = INT_MAX;
+                for (int j = head_c2[b]; j >= 0; j = next_c[j] == 0xffff ? -1 : (int)next_c[j])
+                    if (j < i) D = min(D, (int)(claim_c[j] >> 20));
+                return D;
+            };
+            unsigned long long m1 = ~0ull;
+            for (int e = tid & 63; e < c; e += 64) {
+                const unsigned long long v = list[e];
+                if (left_on((int)(v & 0xfffffu)) > (int)(v >> 32)) m1 = v < m1 ? v : m1;
+            }
+            const unsigned long long k1v = wave_min_u64(m1);
+            unsigned long long m2 = ~0ull;
+            for (int e = tid & 63; e < c; e += 64) {
+                const unsigned long long v = list[e];
+                if (v != k1v && left_on((int)(v & 0xfffffu)) > (int)(v >> 32)) m2 = v < m2 ? v : m2;
+            }
+            const unsigned long long k2v = wave_min_u64(m2);
+            if ((tid & 63) == 0) {
+                uint32_t mine = kNoClaim;
+                if (k1v != ~0ull) {
+                    const int d1 = (int)(k1v >> 32), d2 = k2v == ~0ull ? INT_MAX : (int)(k2v >> 32);
+                    if (d1 <= TH_LOW && (float)d1 < __fmul_rn((float)d2, nnratio)) mine = ((uint32_t)d1 << 20) | (uint32_t)(k1v & 0xfffffu);
+                }
+                claim_n[i] = mine;
+                if (mine != kNoClaim) {
+                    const int old = atomicExch(&head_n[(int)(mine & 0xfffffu)], i);
+                    next_n[i] = old < 0 ? (unsigned short)0xffff : (unsigned short)old;
+                }
+                ch |= mine != claim_c[i];
+            }
         }
         if (ch) S.vars[f_cur] = 1;
         __syncthreads();
