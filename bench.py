@@ -187,6 +187,18 @@ def timed(fn, sync, steps, min_s, allreduce_max=None):
     return dt, reps
 
 
+_REAL_STDOUT = None
+
+
+def emit_json(obj):
+    """The one JSON line of the run, on the process's original stdout."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +226,14 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
+
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner and Gloo its rendezvous messages
+    # to fd 1 from native code, so fd 1 is pointed at stderr for the lifetime of the run and the line goes to a duplicate
+    # of the original descriptor
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -529,7 +549,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames[:16])
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        emit_json(out)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
@@ -708,12 +728,12 @@ def dry_run(args, dist, torch, world, rank, multi, my_pairs, gather_to_rank0):
     if multi:
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "dry run: control flow only, no extraction", "value": None, "unit": "frames/s",
+        emit_json({"metric": "dry run: control flow only, no extraction", "value": None, "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                           "config": {"workload": "dry run (gloo, no GPU): pair sharding + gather of fabricated slots",
                                      "pairs_per_rank": len(my_pairs), "parallelism": "pair-sharded x%d" % world},
-                          "gather_verified": bool(ok)}))
+                          "gather_verified": bool(ok)})
     if multi:
         dist.destroy_process_group()
     if rank == 0 and not ok:
