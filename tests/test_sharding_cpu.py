@@ -94,7 +94,8 @@ def test_bench_self_launches_two_ranks_gloo_dry_run():
                         "--steps", "2", "--warmup", "0", "--frames-per-gpu", "8"], capture_output=True, text=True, env=env,
                        timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must carry the one JSON line only (Gloo / RCCL banners belong on stderr): %r" % lines
+    out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["gather_verified"] is True
     assert out["config"]["pairs_per_rank"] == 4 and out["config"]["parallelism"] == "pair-sharded x2"
