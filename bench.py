@@ -219,6 +219,8 @@ def main():
                          "gather run on fabricated result slots; no extraction, no throughput claim")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: run the multi-rank code path (RCCL init, gather, all_reduce) even with one rank")
+    ap.add_argument("--out-buffers", type=int, default=4,
+                    help="multi-GPU: output sets per rank that rotate between the pipelines and the gather stream (>= 2)")
     ap.add_argument("--handles", type=int, default=3,
                     help="pipelines per GPU; the per-GPU batch is split evenly between them and they run concurrently "
                          "on separate HIP streams (extractor + matcher handle each)")
@@ -345,13 +347,13 @@ def main():
         d_world[0::2, :, 2] = z
 
     obuf = [out_set()]
-    nbuf = 2 if multi and not rehearsal else 1
+    nbuf = args.out_buffers if multi and not rehearsal else 1
     for _ in range(nbuf - 1):
         obuf.append(out_set())
-    gstream = torch.cuda.Stream(dev) if nbuf == 2 else None
-    gdone = [None, None]
+    gstream = torch.cuda.Stream(dev) if nbuf >= 2 else None
+    gdone = [None] * nbuf
     gout = None
-    if nbuf == 2 and rank == 0:
+    if nbuf >= 2 and rank == 0:
         gout = [torch.zeros((world, flat_bytes), dtype=torch.uint8, device=dev)]   # rank-major, same carve-up per rank
     stepno = [0]
     # torch events around the matching of pipeline 0 (recorded on the stream its launches go to): a ring of 256 pairs
