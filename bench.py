@@ -465,12 +465,6 @@ def main():
     stage_alone = exts[0].stage_times_us()
     exts[0].set_profiling(False)
 
-    if os.environ.get("ORBHIP_DEV_STATS"):
-        import ctypes as C
-        from orb_slam2_comment_amd.capi import lib
-        z = (C.c_uint * 4)()
-        lib().orbhip_dev_resolve_stats(z)
-        print("[bench] resolve rounds: workgroups %d, mean %.2f, max %d" % (z[0], z[1] / max(z[0], 1), z[2]), file=sys.stderr, flush=True)
     if rank == 0:
         print("[bench] headline done: %.1f frames/s; secondary legs ..." % (B * world * reps * args.steps / dt_long), file=sys.stderr, flush=True)
     secondary = None

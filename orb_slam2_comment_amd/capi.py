@@ -135,6 +135,14 @@ class OrbHipError(RuntimeError):
         self.code = code
 
 
+def use_library(path):
+    """Point the loader at another build of the library (tools/: the -DORBHIP_DEVTOOLS build).  Before the first lib()."""
+    global LIB_PATH
+    if _LIB is not None:
+        raise RuntimeError("liborbhip is already loaded")
+    LIB_PATH = path
+
+
 def lib():
     """Load liborbhip.so and bind every declared symbol.  Raises if it is missing."""
     global _LIB

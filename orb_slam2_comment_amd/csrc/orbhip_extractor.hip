@@ -135,60 +135,11 @@ __device__ __forceinline__ void det_sincos(float angle_rad, float *c, float *s)
 // ---------------------------------------------------------------------------
 // K1: pyramid.  Level 0 = copyMakeBorder(image, REFLECT_101); level l =
 // resize(level l-1, INTER_LINEAR) + copyMakeBorder (ORBextractor.cc:1107-1132).
-// One thread produces 4 consecutive bytes of the padded destination row
-// (one dword store); border pixels recompute the reflected interior pixel.
+// The table-driven kernels further down are the default path; k_pyr_resize is the
+// general kernel for levels whose tap groups do not fit an 8-byte source window
+// (scale factors > 2.3): one thread produces 4 consecutive bytes of 4 padded
+// destination rows, border pixels recompute the reflected interior pixel.
 // ---------------------------------------------------------------------------
-constexpr int kL0Q = 2;   // 16-byte groups per thread of k_pyr_level0
-__global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ images, int stride,
-                                                    size_t frame_stride, uint8_t *__restrict__ pyr,
-                                                    PyrGeom G)
-{
-    // one thread = kL0Q x 16 bytes of the padded destination row (uint4 stores).  Interior groups read their 16
-    // source bytes with one byte-aligned 16-byte load (image rows have an odd stride; the hardware takes unaligned
-    // global loads); groups touching the REFLECT_101 frame or the row ends go byte by byte.
-    const LevelGeom L = G.lv[0];
-    const int quads = L.pitch >> 4, units = (quads + kL0Q - 1) / kL0Q;
-    int bx, fr;
-    xcd_remap(bx, fr);
-    const int idx = bx * 256 + threadIdx.x;
-    if (idx >= units * L.prows) return;
-    const int py = idx / units, pu = idx - py * units;
-    const uint8_t *src = images + (size_t)fr * frame_stride;
-    uint8_t *dst = pyr + (size_t)fr * G.frame_bytes + L.plane_off;
-    const int sy = reflect101(py - kEdge, L.h);
-    const uint8_t *srow = src + (size_t)sy * stride;
-    uint8_t *drow = dst + (size_t)py * L.pitch;
-    uint4 out[kL0Q];
-#pragma unroll
-    for (int q = 0; q < kL0Q; ++q) {
-        const int pq = min(pu * kL0Q + q, quads - 1);   // the tail repeats the last group (same bytes stored twice)
-        const int x0 = pq * 16 - kPadL;
-        if (x0 >= 0 && x0 + 16 <= L.w) {
-            __builtin_memcpy(&out[q], srow + x0, 16);
-        } else {
-            uint32_t o4[4];
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                uint32_t acc = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int x = x0 + 4 * w + k;
-                    uint32_t v = 0;
-                    if (x >= -kEdge && x < L.w + kEdge) v = srow[reflect101(x, L.w)];
-                    acc |= v << (8 * k);
-                }
-                o4[w] = acc;
-            }
-            out[q] = make_uint4(o4[0], o4[1], o4[2], o4[3]);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < kL0Q; ++q) {
-        const int pq = min(pu * kL0Q + q, quads - 1);
-        *reinterpret_cast<uint4 *>(drow + pq * 16) = out[q];
-    }
-}
-
 // resize(INTER_LINEAR, 8U) in OpenCV's fixed-point arithmetic.  A thread derives the source column / row and the
 // Q11 coefficient pair of each of its 4 destination columns and 4 rows in registers (resize_coef).  Groups whose four
 // taps fit one 8-byte source window (always, for scale factors <= 2.3) take the fast path: one byte-aligned 8-byte
@@ -530,9 +481,11 @@ __device__ __forceinline__ int add_lane_bit(int x, unsigned long long mask)
     return r;
 }
 
-// Diagnostic build only (STAMPS = true, never launched by the product path): per-phase s_memtime sums of all waves,
-// read by tools/fast_ab.py through orbhip_dev_fast_stamps.  Shares, not lengths, are meaningful (the stamps fence).
+// Diagnostic build only (STAMPS = true is instantiated under -DORBHIP_DEVTOOLS alone): per-phase s_memtime sums of all
+// waves, read by tools/fast_ab.py through orbhip_dev_fast_stamps.  Shares, not lengths, are meaningful (the stamps fence).
+#ifdef ORBHIP_DEVTOOLS
 __device__ unsigned long long g_fast_stamps[8];
+#endif
 __device__ __forceinline__ unsigned long long stamp_now()
 {
     unsigned long long t;
@@ -584,7 +537,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         return;
     }
     FAST_STAMP(0);   // prologue
-    if (P.dev == 3) { if (lane == 0) cell_cnt[out_cell] = 0; return; }   // development: launch floor
+#ifdef ORBHIP_DEVTOOLS
+    if (P.dev == 3) { if (lane == 0) cell_cnt[out_cell] = 0; return; }   // timing floor: launch + prologue only
+#endif
     // LDS column of sub-image x: col = x + a + 4 (a = misalignment of x0; the dword on the left holds real pixels).
     // Lane = (row mod RPI, dword column); a batch is U row groups, all loads issued before the first LDS store.  Row
     // groups past the sub-image re-read its last rows (scalar clamp) into LDS rows that nothing looks at.
@@ -607,7 +562,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     for (int i = lane; i < (dh + 2) * (SS / 4); i += 64) sscore[i] = 0;
     __syncthreads();
     FAST_STAMP(1);   // staging (global -> LDS) + score-map clear
-    if (P.dev == 4) { if (lane == 0) cell_cnt[out_cell] = (int)simg[lane] & 0; return; }   // development: staging floor
+#ifdef ORBHIP_DEVTOOLS
+    if (P.dev == 4) { if (lane == 0) cell_cnt[out_cell] = (int)simg[lane] & 0; return; }   // timing floor: + staging
+#endif
 
     // column groups: group g covers LDS cols 4g..4g+3; valid centre cols [c_lo, c_hi)
     constexpr int a = kFastLead;                        // every cell is staged with the same lead (bind_geometry)
@@ -759,6 +716,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         __syncthreads();
     }
     if (lane == 0) cell_cnt[out_cell] = min(total, P.slot_cap);
+#ifdef ORBHIP_DEVTOOLS
     if constexpr (STAMPS) {
         if (lane == 0 && (cell & 63) == 0) {   // one wave in 64 reports (78,080 waves on six addresses would serialise)
 #pragma unroll
@@ -766,6 +724,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             atomicAdd(&g_fast_stamps[7], 1ull);
         }
     }
+#endif
 #undef FAST_STAMP
 }
 
@@ -1279,178 +1238,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     }
 }
 
-// ---------------------------------------------------------------------------
-// K5+K7: IC_Angle (:77-104) + steered rBRIEF (:108-147) + output assembly
-// (:1095-1103), one wavefront per keypoint (4 per workgroup, no workgroup barrier).
-//  * everything that depends only on the slot (level, output index, plane base) is wave-uniform and
-//    computed on the scalar unit;
-//  * moments: the 749 disc pixels are spread over the 64 lanes, 12 per lane; their byte offsets come from
-//    a host-built per-level table (v * pitch + u), the (u, v) weights as int16 pairs, so a pair of pixels
-//    costs one pack + two v_dot2_i32_i16; shuffle reduction;
-//  * the 37 x 40-byte blurred patch the descriptor samples (|rotated offset| <= 18) is fetched in the SAME
-//    memory round trip as the disc pixels (its address does not depend on the angle) into this wavefront's
-//    LDS tile: lane = (row mod 6, dword column), 7 loads per lane;
-//  * descriptor: test t = 64*j + lane with the pattern as a float4 table (x0, y0, x1, y1), so four 64-bit
-//    ballots are the 32 descriptor bytes (LSB-first) directly.
-// ---------------------------------------------------------------------------
-constexpr int kPatchDw = 10;     // dwords per staged patch row: 37 bytes starting at most 3 bytes into the first dword
-constexpr int kPatchRows = 37;
-constexpr int kPatchRpi = 6;     // rows per staging instruction (60 of 64 lanes)
-constexpr int kDescPerWave = 2;  // consecutive keypoint slots per wavefront (1: 65 us, 2: 60 us, 4: 65 us, 8: 88 us per 64 frames)
-constexpr int kDiscDw = 9;       // dwords per staged row of the 31 x 31 orientation window (31 bytes starting <= 3 bytes in)
-constexpr int kDiscRows = 31;
-constexpr int kDiscRpi = 7;      // rows per staging instruction (63 of 64 lanes)
-
-__global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restrict__ pyr,
-                                                         const uint8_t *__restrict__ blur, PyrGeom G,
-                                                         const uint32_t *__restrict__ sel_kp,
-                                                         const int *__restrict__ sel_cnt,
-                                                         const DiscTab *__restrict__ disc,
-                                                         const int *__restrict__ disc_off,
-                                                         const float4 *__restrict__ patternf,
-                                                         orbhip_keypoint *__restrict__ out_kp,
-                                                         uint8_t *__restrict__ out_desc, int cap,
-                                                         int *__restrict__ out_n, int *__restrict__ status, int per_wave)
-{
-    __shared__ uint32_t spatch[4][kPatchRows * kPatchDw + 8];
-    __shared__ uint32_t sdisc[4][kDiscRows * kDiscDw + 8];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int bx, b;
-    xcd_remap(bx, b);
-    // per-lane constants of the whole kernel stay in registers across the kDescPerWave keypoints of this wavefront:
-    // the (u, v) weights of its 12 disc pixels and its 4 rBRIEF test pairs; the byte offsets of the disc pixels
-    // depend on the level's pitch and are reloaded when the level changes (slots are level-major: rarely)
-    uint32_t u2[6], v2[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { u2[k] = disc->u2[k * 64 + lane]; v2[k] = disc->v2[k * 64 + lane]; }
-    float4 pat[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pat[j] = patternf[j * 64 + lane];
-    int dl[12];   // byte offset of this lane's 12 disc pixels inside the staged 31-row tile: (v + 15) * 36 + (u + 15)
-#pragma unroll
-    for (int k = 0; k < 12; ++k) dl[k] = disc_off[k * 64 + lane];
-    const int *cnts = sel_cnt + b * ORBHIP_MAX_LEVELS;
-    int total = 0;
-    for (int l = 0; l < G.nlevels; ++l) total += cnts[l];
-    if (bx == 0 && wv == 0 && lane == 0) {
-        out_n[b] = min(total, cap);
-        if (total > cap && status) atomicExch(&status[b], ORBHIP_E_CAPACITY);
-    }
-    const int prow = lane / kPatchDw, pcol = lane - prow * kPatchDw;   // patch staging: lanes 60..63 idle
-    const int drow = lane / kDiscDw, dcol = lane - drow * kDiscDw;     // disc staging: lane 63 idle
-    uint32_t *patch = spatch[wv];
-    uint32_t *dtile = sdisc[wv];
-  for (int kk = 0; kk < per_wave; ++kk) {
-    const int slot = (bx * 4 + wv) * per_wave + kk;  // wave-uniform: everything up to the pixel loads is scalar work
-    if (slot >= G.kp_cap_total) break;
-    int level = 0;
-    for (int l = 1; l < G.nlevels; ++l) if (slot >= G.lv[l].kp_base) level = l;
-    int before = 0, mine = 0;
-    for (int l = 0; l < G.nlevels; ++l) {
-        const int c = cnts[l];
-        if (l < level) before += c;
-        if (l == level) mine = c;
-    }
-    const int kp_base = G.lv[level].kp_base, pitch = G.lv[level].pitch;
-    const int i = slot - kp_base;
-    if (i >= mine) continue;
-    const int oidx = before + i;
-    if (oidx >= cap) continue;
-
-    const uint32_t kv = sel_kp[(size_t)b * G.kp_cap_total + slot];
-    const int kx = (int)(kv & 0xfff) + 16, ky = (int)((kv >> 12) & 0xfff) + 16;  // + minBorder (:843-844)
-    const int resp = (int)(kv >> 24);
-    const size_t fo = (size_t)b * G.frame_bytes + G.lv[level].plane_off + (size_t)kEdge * pitch + kPadL;
-    const uint8_t *c = pyr + fo + (size_t)ky * pitch + kx;          // keypoint in the unblurred level (uniform)
-    // ---- issue every load of the round trip: the 31-row disc window of the unblurred level and the blurred patch,
-    // both as aligned dwords (lane = (row mod R, dword column)); the per-pixel reads then come from LDS ----
-    const int xd = (kx - 15) & ~3;                                  // dword-aligned ROI column of disc-tile column 0
-    const uint8_t *db = c - (size_t)15 * pitch - (kx - xd);
-    uint32_t dv[5];
-    {
-        const uint32_t voff = (uint32_t)(__mul24(drow, pitch) + 4 * dcol);
-#pragma unroll
-        for (int u = 0; u < 5; ++u)
-            dv[u] = (lane < kDiscRpi * kDiscDw) ? *reinterpret_cast<const uint32_t *>(db + (uint32_t)(u * kDiscRpi * pitch) + voff) : 0u;
-    }
-    const int xs = (kx - 18) & ~3;                                  // dword-aligned ROI column of patch column 0
-    const uint8_t *bb = blur + fo + (size_t)(ky - 18) * pitch + xs;
-    uint32_t pv[7];
-    {
-        const uint32_t voff = (uint32_t)(__mul24(prow, pitch) + 4 * pcol);
-#pragma unroll
-        for (int u = 0; u < 7; ++u)
-            pv[u] = (lane < kPatchRpi * kPatchDw) ? *reinterpret_cast<const uint32_t *>(bb + (uint32_t)(u * kPatchRpi * pitch) + voff) : 0u;
-    }
-    __builtin_amdgcn_wave_barrier();                     // the previous keypoint's LDS reads are done
-    {
-        uint32_t *dd = dtile + (drow * kDiscDw + dcol);
-        if (lane < kDiscRpi * kDiscDw) {
-#pragma unroll
-            for (int u = 0; u < 5; ++u)
-                if (u < 4 || drow < kDiscRows - 4 * kDiscRpi) dd[u * kDiscRpi * kDiscDw] = dv[u];   // rows 28..34: only 28..30 exist
-        }
-        uint32_t *pd = patch + (prow * kPatchDw + pcol);
-        if (lane < kPatchRpi * kPatchDw) {
-#pragma unroll
-            for (int u = 0; u < 7; ++u)
-                if (u < 6 || prow == 0) pd[u * kPatchRpi * kPatchDw] = pv[u];    // rows 36..41: only row 36 exists
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- moments ----
-    int m10 = 0, m01 = 0;
-    {
-        const uint8_t *d8 = reinterpret_cast<const uint8_t *>(dtile) + (kx - 15 - xd);
-        int pix[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) pix[k] = d8[dl[k]];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const uint32_t p2 = (uint32_t)pix[2 * k] | ((uint32_t)pix[2 * k + 1] << 16);
-            m10 = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, p2), __builtin_bit_cast(i16x2_t, u2[k]), m10, false);
-            m01 = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, p2), __builtin_bit_cast(i16x2_t, v2[k]), m01, false);
-        }
-    }
-    m10 = wave_reduce_add(m10);
-    m01 = wave_reduce_add(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, bsn;
-    det_sincos(__fmul_rn(angle, factorPI), &a, &bsn);
-    __builtin_amdgcn_wave_barrier();                     // the tile is private to this wavefront; DS ops are in order
-    const uint8_t *cb = reinterpret_cast<const uint8_t *>(patch) + 18 * (kPatchDw * 4) + (kx - xs);   // patch byte of the keypoint
-    unsigned long long bits[4];
-    int t0v[4], t1v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float px0 = pat[j].x, py0 = pat[j].y, px1 = pat[j].z, py1 = pat[j].w;
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, bsn), __fmul_rn(py0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, bsn)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, bsn), __fmul_rn(py1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, bsn)));
-        t0v[j] = cb[__mul24(r0, kPatchDw * 4) + c0];
-        t1v[j] = cb[__mul24(r1, kPatchDw * 4) + c1];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bits[j] = __ballot(t0v[j] < t1v[j]);
-    if (lane < 4) {
-        unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-        reinterpret_cast<unsigned long long *>(out_desc + ((size_t)b * cap + oidx) * 32)[lane] = v;
-    }
-    if (lane == 0) {
-        orbhip_keypoint kp;
-        float fx = (float)kx, fy = (float)ky;
-        const float scale = G.lv[level].scale;
-        if (level != 0) { fx = __fmul_rn(fx, scale); fy = __fmul_rn(fy, scale); }
-        kp.x = fx; kp.y = fy; kp.size = (float)G.lv[level].patch; kp.angle = angle; kp.response = (float)resp;
-        kp.octave = level; kp.class_id = -1;
-        out_kp[(size_t)b * cap + oidx] = kp;
-    }
-  }
-}
+constexpr int kDescPerWave = 2;  // consecutive keypoint slots per wavefront (1: 86 us, 2: 64 us, 3: 79 us, 4: 79 us per 64 frames)
 
 // ---------------------------------------------------------------------------
 // K5+K6+K7 fused: IC_Angle + GaussianBlur(7x7) of the patch + steered rBRIEF, one wavefront per keypoint.
@@ -1656,6 +1444,14 @@ __global__ void k_zero_status(int *status, int n)
 // ===========================================================================
 using namespace orbhip;
 
+// Development builds (-DORBHIP_DEVTOOLS, tools/ab_build.sh) can run a subset of the stages on buffers a full run left
+// behind (tools/coexec.py) and launch the stamped FAST kernel (tools/fast_ab.py); the product library has neither.
+#ifdef ORBHIP_DEVTOOLS
+#define ORBHIP_STAGE_MASK(e) ((e)->stage_mask)
+#else
+#define ORBHIP_STAGE_MASK(e) 31
+#endif
+
 static int cv_round(double v) { return (int)lrint(v); }
 
 static void drop_graph(orbhip_extractor *e)
@@ -1678,6 +1474,7 @@ static void free_batch(orbhip_extractor *e)
     e->d_pyr = e->d_blur = nullptr; e->d_cell_cnt = nullptr; e->d_cell_kp = nullptr; e->d_keys = nullptr;
     e->d_knode = nullptr; e->d_sel = nullptr; e->d_sel_cnt = nullptr; e->d_status = nullptr;
     e->batch_cap = 0;
+    e->blur_valid = false;
 }
 
 // OpenCV's fixed-point bilinear coefficients of one destination coordinate (the host twin of resize_coef):
@@ -1988,13 +1785,6 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
     return ORBHIP_OK;
 }
 
-// development switch: blur kernel + unfused orientation / descriptor kernel (the round-1 structure)
-static bool dev_separate_blur()
-{
-    static const bool on = getenv("ORBHIP_SEPARATE_BLUR") != nullptr;
-    return on;
-}
-
 static int ensure_batch(orbhip_extractor *e, int batch)
 {
     if (batch <= e->batch_cap) return ORBHIP_OK;
@@ -2002,8 +1792,7 @@ static int ensure_batch(orbhip_extractor *e, int batch)
     free_batch(e);
     const PyrGeom &G = e->G;
     const size_t B = (size_t)batch;
-    ORBHIP_HIP_CHECK(hipMalloc(&e->d_pyr, B * G.frame_bytes));
-    if (dev_separate_blur()) ORBHIP_HIP_CHECK(hipMalloc(&e->d_blur, B * G.frame_bytes));   // otherwise allocated when a blurred plane is asked for
+    ORBHIP_HIP_CHECK(hipMalloc(&e->d_pyr, B * G.frame_bytes));   // d_blur: allocated when a blurred plane is asked for
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_cell_cnt, B * std::max(G.ncells_total, 1) * sizeof(int)));
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_cell_kp, B * std::max(G.ncells_total, 1) * G.slot_cap * sizeof(uint32_t)));
     ORBHIP_HIP_CHECK(hipMalloc(&e->d_keys, B * G.cand_cap_total * sizeof(uint32_t)));
@@ -2015,6 +1804,14 @@ static int ensure_batch(orbhip_extractor *e, int batch)
     return ORBHIP_OK;
 }
 
+// Every extraction entry calls this before it enqueues anything: whatever the accessors cached about the previous
+// batch (the lazily produced blurred planes) is stale from here on -- also when the work itself is a graph replay that
+// never passes through launch_pipeline.
+static void begin_extraction(orbhip_extractor *e)
+{
+    e->blur_valid = false;
+}
+
 // `frame0`: first internal frame slot of this launch (the host path runs a batch as several chunks, each in its own
 // slots, so that every frame's pyramid stays resident for orbhip_pyramid_level / ComputeStereoMatches afterwards)
 static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int batch, int stride,
@@ -2024,8 +1821,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     const PyrGeom &G = e->G;
     hipStream_t s = e->stream;
     // per-frame internal buffers of this launch
-    const bool dev_sep = dev_separate_blur();
-    uint8_t *const b_pyr = e->d_pyr + (size_t)frame0 * G.frame_bytes, *const b_blur = e->d_blur ? e->d_blur + (size_t)frame0 * G.frame_bytes : nullptr;
+    uint8_t *const b_pyr = e->d_pyr + (size_t)frame0 * G.frame_bytes;
     int *const b_cell_cnt = e->d_cell_cnt + (size_t)frame0 * std::max(G.ncells_total, 1);
     uint32_t *const b_cell_kp = e->d_cell_kp + (size_t)frame0 * std::max(G.ncells_total, 1) * G.slot_cap;
     uint32_t *const b_keys = e->d_keys + (size_t)frame0 * G.cand_cap_total;
@@ -2035,31 +1831,20 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     const bool prof = e->profiling;
     hipEvent_t *ev = prof ? &e->ev[(size_t)(e->prof_calls % orbhip_extractor::kProfRing) * orbhip_extractor::kProfEv] : nullptr;
     int *status = d_status ? d_status : e->d_status + frame0;
-    static const bool dev_old_pyr = getenv("ORBHIP_PYR_GENERAL") != nullptr;
-    if (dev_old_pyr || !(e->stage_mask & 1))   // k_pyr_base clears the status words itself
+    const int sm = ORBHIP_STAGE_MASK(e);
+    if (!(sm & 1))   // k_pyr_base clears the status words itself
         hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
     if (prof) (void)hipEventRecord(ev[0], s);
-    const int sm = e->stage_mask;   // development switch (tools/coexec.py): run a subset of the stages on buffers a full run left
     if (sm & 1) {
-        static const bool dev_old = getenv("ORBHIP_PYR_GENERAL") != nullptr;   // development switch: the general kernels for every level
         // level 0 and, when its taps allow, level 1 in one launch
-        const bool l1_rows = G.nlevels > 1 && e->ptab_rows[1] && !dev_old;
-        int first = 1;
-        if (!dev_old) {
-            PyrLevelTab T1 = e->ptab[1];
-            if (!l1_rows) memset(&T1, 0, sizeof(T1));
-            const int nb0 = (e->ptab[0].units + 3) / 4, nb1 = (T1.units + 3) / 4;
-            hipLaunchKernelGGL(k_pyr_base, dim3(nb0 + nb1, batch), dim3(256), 0, s, d_images, stride, frame_stride, b_pyr,
-                               G.frame_bytes, e->ptab[0], T1, nb0, status);
-            if (l1_rows) first = 2;
-        } else {
-            const LevelGeom &L = G.lv[0];
-            int n = (((L.pitch >> 4) + kL0Q - 1) / kL0Q) * L.prows;
-            hipLaunchKernelGGL(k_pyr_level0, dim3((n + 255) / 256, batch), dim3(256), 0, s, d_images, stride,
-                               frame_stride, b_pyr, G);
-        }
-        for (int l = first; l < G.nlevels; ++l) {
-            if (e->ptab_rows[l] && !dev_old) {
+        const bool l1_rows = G.nlevels > 1 && e->ptab_rows[1];
+        PyrLevelTab T1 = e->ptab[1];
+        if (!l1_rows) memset(&T1, 0, sizeof(T1));
+        const int nb0 = (e->ptab[0].units + 3) / 4, nb1 = (T1.units + 3) / 4;
+        hipLaunchKernelGGL(k_pyr_base, dim3(nb0 + nb1, batch), dim3(256), 0, s, d_images, stride, frame_stride, b_pyr,
+                           G.frame_bytes, e->ptab[0], T1, nb0, status);
+        for (int l = l1_rows ? 2 : 1; l < G.nlevels; ++l) {
+            if (e->ptab_rows[l]) {
                 hipLaunchKernelGGL(k_pyr_rows, dim3((e->ptab[l].units + 3) / 4, batch), dim3(256), 0, s, b_pyr, G.frame_bytes, e->ptab[l]);
                 continue;
             }
@@ -2075,16 +1860,19 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         const dim3 grid(G.ncells_total, batch);
         const size_t lb = (size_t)e->fast_lds_bytes;
         FastParams P = e->fast_params;
-        P.dev = e->fast_variant;
         // remap: frame = lin2 / ncells by multiplication; exact while lin2 * ncells < 2^32
         P.rcp_cells = (uint32_t)(((1ull << 32) + (unsigned)G.ncells_total - 1) / (unsigned)G.ncells_total);
         if ((unsigned long long)G.ncells_total * G.ncells_total * (unsigned long long)batch >= (1ull << 32)) {
             set_error("batch too large for the FAST kernel's work mapping"); return ORBHIP_E_SIZE;
         }
 #define ORBHIP_FAST2(SWv) hipLaunchKernelGGL(k_fast_cells<SWv>, grid, dim3(64), lb, s, b_pyr, e->d_cells2, b_cell_cnt, b_cell_kp, P)
+#ifdef ORBHIP_DEVTOOLS
+        P.dev = e->fast_variant;
         if (e->fast_variant == 2 && e->fast_lds.strideW == 11)   // stamped diagnostic build (tools/fast_ab.py)
             hipLaunchKernelGGL((k_fast_cells<11, true>), grid, dim3(64), lb, s, b_pyr, e->d_cells2, b_cell_cnt, b_cell_kp, P);
-        else switch (e->fast_lds.strideW) {
+        else
+#endif
+        switch (e->fast_lds.strideW) {
         case 11: ORBHIP_FAST2(11); break;
         case 13: ORBHIP_FAST2(13); break;
         case 15: ORBHIP_FAST2(15); break;
@@ -2106,26 +1894,15 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
 #undef ORBHIP_OCT
     }
     if (prof) (void)hipEventRecord(ev[3], s);
-    // The blur only needs the pyramid.  Forking it onto a second stream beside FAST/octree was measured: it buys
-    // nothing once two pipelines (handles) run concurrently and makes throughput depend on how the runtime maps
-    // streams to hardware queues (122 k vs 136 k frames/s run to run), so it stays in order on this stream.
-    if ((sm & 8) && dev_sep) hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, s, b_pyr, b_blur, G,
-                                                e->d_tiles, e->blurw);
-    if (prof) (void)hipEventRecord(ev[4], s);
     if (sm & 16) {
-        static const int dev_pw = getenv("ORBHIP_DESC_PER_WAVE") ? atoi(getenv("ORBHIP_DESC_PER_WAVE")) : 0;
-        const int pw = dev_pw > 0 ? dev_pw : kDescPerWave;
-        const dim3 grid((G.kp_cap_total + 4 * pw - 1) / (4 * pw), batch);
-        if (dev_sep)
-            hipLaunchKernelGGL(k_orient_describe, grid, dim3(256), 0, s, b_pyr, b_blur,
-                               G, b_sel, b_sel_cnt, e->d_disc, e->d_disc_off, e->d_patternf, d_kps, d_desc, cap, d_n, status, pw);
-        else
-            hipLaunchKernelGGL(k_describe_fused, grid, dim3(256), 0, s, b_pyr, G, b_sel, b_sel_cnt, e->d_disc, e->d_disc_off2,
-                               e->d_patternf, d_kps, d_desc, cap, d_n, status, pw, e->blurw,
-                               reinterpret_cast<const uint32_t *>(e->d_disc_off2 + 768));
+        // IC_Angle + the 7x7 blur of the keypoint's patch + rBRIEF in one kernel: no blurred plane exists unless
+        // orbhip_blurred_level_download asks for one
+        const dim3 grid((G.kp_cap_total + 4 * kDescPerWave - 1) / (4 * kDescPerWave), batch);
+        hipLaunchKernelGGL(k_describe_fused, grid, dim3(256), 0, s, b_pyr, G, b_sel, b_sel_cnt, e->d_disc, e->d_disc_off2,
+                           e->d_patternf, d_kps, d_desc, cap, d_n, status, kDescPerWave, e->blurw,
+                           reinterpret_cast<const uint32_t *>(e->d_disc_off2 + 768));
     }
-    e->blur_valid = dev_sep;
-    if (prof) { (void)hipEventRecord(ev[5], s); e->prof_calls++; }
+    if (prof) { (void)hipEventRecord(ev[4], s); e->prof_calls++; }
     e->last_batch = frame0 + batch;
     ORBHIP_HIP_CHECK(hipGetLastError());
     return ORBHIP_OK;
@@ -2317,6 +2094,7 @@ int orbhip_extract_batch_device(orbhip_extractor *e, const void *d_images, int b
     if (rc) return rc;
     rc = ensure_batch(e, batch);
     if (rc) return rc;
+    begin_extraction(e);
     return launch_pipeline(e, (const uint8_t *)d_images, batch, stride, frame_stride, (orbhip_keypoint *)d_kps,
                            (uint8_t *)d_desc, cap, (int *)d_n, (int *)d_status);
 }
@@ -2333,8 +2111,22 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
     ORBHIP_HIP_CHECK(hipSetDevice(e->device));
     int rc = bind_geometry(e, rows, cols);
     if (rc) return rc;
-    // staging buffers
-    const size_t img_bytes = (size_t)batch * rows * cols;
+    // Large batches run as a software pipeline of 16-frame chunks on three streams (below).  There, a caller that keeps its
+    // images in page-locked memory (hipHostMalloc / hipHostRegister, e.g. a pinned cv::Mat allocator) skips the staging
+    // copy: the DMA engine reads every frame where it is with ONE 1-D copy of its rows in the caller's own row stride,
+    // and the kernels read that layout (the stride is a kernel argument) -- no transfer is ever a rectangle copy.
+    constexpr int kChunk = 16;
+    const bool chunked = batch >= 2 * kChunk && !e->profiling;
+    bool pinned_src = false;
+    if (chunked) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, images) == hipSuccess) pinned_src = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();   // pageable memory is "invalid value" for this query: not an error here
+    }
+    const int dstride = pinned_src ? stride : cols;                   // row stride of the frames in the device staging
+    const size_t fbytes = (size_t)rows * dstride;                     // one frame slot there
+    const size_t fcopy = (size_t)(rows - 1) * dstride + cols;         // bytes of a frame that are ever read
+    const size_t img_bytes = (size_t)batch * fbytes;
     if (img_bytes > e->d_img_bytes) {
         drop_graph(e);
         (void)hipFree(e->d_img); e->d_img = nullptr; e->d_img_bytes = 0;
@@ -2346,15 +2138,14 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
         (void)hipFree(e->d_okp); (void)hipFree(e->d_odesc); (void)hipFree(e->d_on);
         e->d_okp = nullptr; e->d_odesc = nullptr; e->d_on = nullptr;
         e->out_slots = 0; e->out_batch = 0;
-        const size_t slots = std::max((size_t)cap * batch, e->out_slots);
-        const int ob = std::max(batch, e->out_batch);
+        const size_t slots = (size_t)cap * batch;
         ORBHIP_HIP_CHECK(hipMalloc(&e->d_okp, slots * sizeof(orbhip_keypoint)));
         ORBHIP_HIP_CHECK(hipMalloc(&e->d_odesc, slots * 32));
-        ORBHIP_HIP_CHECK(hipMalloc(&e->d_on, (size_t)ob * sizeof(int)));
-        e->out_slots = slots; e->out_batch = ob;
+        ORBHIP_HIP_CHECK(hipMalloc(&e->d_on, (size_t)batch * sizeof(int)));
+        e->out_slots = slots; e->out_batch = batch;
     }
     // host -> pinned staging (row copies on the CPU) -> one DMA
-    if (img_bytes > e->h_in_bytes) {
+    if (!pinned_src && img_bytes > e->h_in_bytes) {
         drop_graph(e);
         if (e->h_in) (void)hipHostFree(e->h_in);
         e->h_in = nullptr; e->h_in_bytes = 0;
@@ -2372,6 +2163,7 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));   // the staging buffer of the previous call is free
     rc = ensure_batch(e, batch);
     if (rc) return rc;
+    begin_extraction(e);
     int *h_n = reinterpret_cast<int *>(e->h_out), *h_st = h_n + batch;
     orbhip_keypoint *h_kp = reinterpret_cast<orbhip_keypoint *>(h_st + batch);
     uint8_t *h_desc = reinterpret_cast<uint8_t *>(h_kp + (size_t)batch * cap);
@@ -2393,12 +2185,10 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
             }
         }
     };
-    // Large batches run as a software pipeline of 16-frame chunks on three streams: while the kernels of chunk k run,
-    // chunk k+1 is copied into pinned memory by the CPU and over PCIe by the DMA engine, and the results of chunk k-1
-    // travel back and are handed to the caller.  What a Tracking thread sees is still one synchronous call.
-    constexpr int kChunk = 16;
-    static const bool no_pipe = getenv("ORBHIP_NO_PIPELINE") != nullptr;
-    if (batch >= 2 * kChunk && !e->profiling && !no_pipe) {
+    // The chunk pipeline: while the kernels of chunk k run, chunk k+1 is copied into pinned memory by the CPU and over
+    // PCIe by the DMA engine, and the results of chunk k-1 travel back and are handed to the caller.  What a Tracking
+    // thread sees is still one synchronous call.
+    if (chunked) {
         if (!e->s_in) {
             ORBHIP_HIP_CHECK(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
             ORBHIP_HIP_CHECK(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
@@ -2409,37 +2199,23 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
             ORBHIP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             e->ev_chunk.push_back(ev);
         }
-        const size_t fbytes = (size_t)rows * cols;
-        static const bool host_timing = getenv("ORBHIP_HOST_TIMING") != nullptr;   // development: where the host time goes
-        double t_stage = 0, t_enq = 0, t_wait = 0, t_deliver = 0;
-        auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
-        // a caller that keeps its images in page-locked memory (hipHostMalloc / hipHostRegister, e.g. a pinned cv::Mat
-        // allocator) skips the staging copy: the DMA engine reads the frames where they are
-        bool pinned_src = false;
-        {
-            hipPointerAttribute_t attr;
-            if (hipPointerGetAttributes(&attr, images) == hipSuccess) pinned_src = attr.type == hipMemoryTypeHost;
-            else (void)hipGetLastError();   // pageable memory is "invalid value" for this query: not an error here
-        }
         for (int c = 0; c < nchunks; ++c) {
             const int b0 = c * kChunk, nb = std::min(kChunk, batch - b0);
             hipEvent_t ev_in = e->ev_chunk[3 * c], ev_k = e->ev_chunk[3 * c + 1], ev_out = e->ev_chunk[3 * c + 2];
-            const double t0 = now();
-            if (!pinned_src) stage_in(b0, nb);
-            const double t1 = now();
-            t_stage += t1 - t0;
             if (pinned_src) {
-                if (stride == cols && frame_stride == fbytes)
-                    ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img + b0 * fbytes, images + b0 * frame_stride, nb * fbytes, hipMemcpyHostToDevice, e->s_in));
+                if (frame_stride == fbytes)        // frames back to back in the caller's layout: one copy per chunk
+                    ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img + b0 * fbytes, images + b0 * frame_stride, (nb - 1) * fbytes + fcopy,
+                                                    hipMemcpyHostToDevice, e->s_in));
                 else
                     for (int b = b0; b < b0 + nb; ++b)
-                        ORBHIP_HIP_CHECK(hipMemcpy2DAsync(e->d_img + b * fbytes, cols, images + b * frame_stride, stride, cols, rows,
-                                                          hipMemcpyHostToDevice, e->s_in));
-            } else
-            ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img + b0 * fbytes, e->h_in + b0 * fbytes, nb * fbytes, hipMemcpyHostToDevice, e->s_in));
+                        ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img + b * fbytes, images + b * frame_stride, fcopy, hipMemcpyHostToDevice, e->s_in));
+            } else {
+                stage_in(b0, nb);
+                ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_img + b0 * fbytes, e->h_in + b0 * fbytes, nb * fbytes, hipMemcpyHostToDevice, e->s_in));
+            }
             ORBHIP_HIP_CHECK(hipEventRecord(ev_in, e->s_in));
             ORBHIP_HIP_CHECK(hipStreamWaitEvent(e->stream, ev_in, 0));
-            rc = launch_pipeline(e, e->d_img + b0 * fbytes, nb, cols, fbytes, e->d_okp + (size_t)b0 * cap, e->d_odesc + (size_t)b0 * cap * 32,
+            rc = launch_pipeline(e, e->d_img + b0 * fbytes, nb, dstride, fbytes, e->d_okp + (size_t)b0 * cap, e->d_odesc + (size_t)b0 * cap * 32,
                                  cap, e->d_on + b0, nullptr, b0);
             if (rc) { (void)hipDeviceSynchronize(); return rc; }
             ORBHIP_HIP_CHECK(hipEventRecord(ev_k, e->stream));
@@ -2451,20 +2227,13 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
             ORBHIP_HIP_CHECK(hipMemcpyAsync(h_desc + (size_t)b0 * cap * 32, e->d_odesc + (size_t)b0 * cap * 32, (size_t)nb * cap * 32,
                                             hipMemcpyDeviceToHost, e->s_out));
             ORBHIP_HIP_CHECK(hipEventRecord(ev_out, e->s_out));
-            t_enq += now() - t1;
         }
         int bad = -1;
         for (int c = 0; c < nchunks; ++c) {
-            const double t0 = now();
             ORBHIP_HIP_CHECK(hipEventSynchronize(e->ev_chunk[3 * c + 2]));
-            const double t1 = now();
             deliver(c * kChunk, std::min(kChunk, batch - c * kChunk), bad);
-            t_wait += t1 - t0; t_deliver += now() - t1;
         }
         ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
-        if (host_timing)
-            fprintf(stderr, "[orbhip] extract_batch %d frames: stage-in %.3f ms, enqueue %.3f ms, wait %.3f ms, deliver %.3f ms\n",
-                    batch, t_stage, t_enq, t_wait, t_deliver);
         if (bad >= 0) { set_error("frame %d: capacity exceeded (cap %d); outputs are truncated", bad, cap); return ORBHIP_E_CAPACITY; }
         return ORBHIP_OK;
     }
@@ -2481,8 +2250,7 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
     };
     // Every pointer and by-value argument of the sequence is fixed for a (geometry, batch, cap, buffers) combination:
     // capture it once, replay it with one launch.  Anything that would change an argument drops the graph.
-    static const bool no_graph = getenv("ORBHIP_NO_GRAPH") != nullptr;
-    if (!e->profiling && !no_graph) {
+    if (!e->profiling) {
         if (!e->graph_exec || e->graph_batch != batch || e->graph_cap != cap) {
             drop_graph(e);
             hipGraph_t graph = nullptr;
@@ -2555,6 +2323,21 @@ int orbhip_pyramid_level(orbhip_extractor *e, int frame, int level, int *rows, i
     return ORBHIP_OK;
 }
 
+// Transfer rule of this library: every copy between host and device is a 1-D hipMemcpyAsync on a stream of the handle,
+// to or from page-locked staging memory the handle owns, followed by a wait on that stream and a CPU copy to / from the
+// caller's memory.  No legacy-stream copies, no rectangle (2-D) copies, no DMA into caller-owned pageable pages.
+static int ensure_host_out(orbhip_extractor *e, size_t bytes)
+{
+    if (bytes <= e->h_out_bytes) return ORBHIP_OK;
+    drop_graph(e);   // a captured sequence holds the old staging pointer
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (e->h_out) (void)hipHostFree(e->h_out);
+    e->h_out = nullptr; e->h_out_bytes = 0;
+    ORBHIP_HIP_CHECK(hipHostMalloc((void **)&e->h_out, bytes, hipHostMallocDefault));
+    e->h_out_bytes = bytes;
+    return ORBHIP_OK;
+}
+
 static int download_plane(orbhip_extractor *e, const uint8_t *base, int frame, int level, int with_border, uint8_t *dst, int dst_stride)
 {
     if (!e || !e->bound || !dst || frame < 0 || frame >= e->last_batch || level < 0 || level >= e->nlevels) return ORBHIP_E_ARG;
@@ -2562,15 +2345,14 @@ static int download_plane(orbhip_extractor *e, const uint8_t *base, int frame, i
     const int bo = with_border ? kEdge : 0;
     const int w = L.w + 2 * bo, h = L.h + 2 * bo;
     if (dst_stride < w) return ORBHIP_E_ARG;
-    // whole padded rows in one contiguous copy on the handle's stream, cropped on the host (a pitched 2-D copy into
-    // pageable memory goes through the runtime's rectangle-copy path, which was seen to deliver a stale plane about once
-    // in a thousand downloads of a randomised sweep)
+    // whole padded rows in one contiguous stream-ordered copy, cropped on the host
     const uint8_t *src = base + (size_t)frame * e->G.frame_bytes + L.plane_off + (size_t)(kEdge - bo) * L.pitch;
     ORBHIP_HIP_CHECK(hipSetDevice(e->device));
-    std::vector<uint8_t> rows((size_t)h * L.pitch);
-    ORBHIP_HIP_CHECK(hipMemcpyAsync(rows.data(), src, rows.size(), hipMemcpyDeviceToHost, e->stream));
+    const size_t bytes = (size_t)h * L.pitch;
+    if (int rc = ensure_host_out(e, bytes)) return rc;
+    ORBHIP_HIP_CHECK(hipMemcpyAsync(e->h_out, src, bytes, hipMemcpyDeviceToHost, e->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
-    for (int r = 0; r < h; ++r) memcpy(dst + (size_t)r * dst_stride, rows.data() + (size_t)r * L.pitch + (kPadL - bo), (size_t)w);
+    for (int r = 0; r < h; ++r) memcpy(dst + (size_t)r * dst_stride, e->h_out + (size_t)r * L.pitch + (kPadL - bo), (size_t)w);
     return ORBHIP_OK;
 }
 
@@ -2600,14 +2382,18 @@ int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *
     const PyrGeom &G = e->G;
     const LevelGeom &L = G.lv[level];
     ORBHIP_HIP_CHECK(hipSetDevice(e->device));
-    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
-    std::vector<int> cnt(std::max(L.ncells, 1));
-    std::vector<uint32_t> kp((size_t)std::max(L.ncells, 1) * G.slot_cap);
+    const size_t cnt_bytes = (size_t)std::max(L.ncells, 1) * sizeof(int);
+    const size_t kp_off = (cnt_bytes + 255) & ~(size_t)255, kp_bytes = (size_t)std::max(L.ncells, 1) * G.slot_cap * sizeof(uint32_t);
+    if (int rc = ensure_host_out(e, kp_off + kp_bytes)) return rc;
+    const int *cnt = reinterpret_cast<const int *>(e->h_out);
+    const uint32_t *kp = reinterpret_cast<const uint32_t *>(e->h_out + kp_off);
     if (L.ncells > 0) {
-        ORBHIP_HIP_CHECK(hipMemcpy(cnt.data(), e->d_cell_cnt + (size_t)frame * G.ncells_total + L.cell_base, L.ncells * sizeof(int), hipMemcpyDeviceToHost));
-        ORBHIP_HIP_CHECK(hipMemcpy(kp.data(), e->d_cell_kp + ((size_t)frame * G.ncells_total + L.cell_base) * G.slot_cap,
-                                   (size_t)L.ncells * G.slot_cap * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(e->h_out, e->d_cell_cnt + (size_t)frame * G.ncells_total + L.cell_base, L.ncells * sizeof(int),
+                                        hipMemcpyDeviceToHost, e->stream));
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(e->h_out + kp_off, e->d_cell_kp + ((size_t)frame * G.ncells_total + L.cell_base) * G.slot_cap,
+                                        (size_t)L.ncells * G.slot_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     }
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
     int k = 0;
     for (int c = 0; c < L.ncells; ++c)
         for (int i = 0; i < cnt[c]; ++i) {
@@ -2619,7 +2405,8 @@ int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *
     return k > cap ? ORBHIP_E_CAPACITY : ORBHIP_OK;
 }
 
-// development switch (not part of include/orbhip.h): 1 = first formulation of the FAST kernel, 0 = current one
+#ifdef ORBHIP_DEVTOOLS
+// development exports (not part of include/orbhip.h, absent from the product library): tools/coexec.py, tools/fast_ab.py
 int orbhip_dev_set_stage_mask(orbhip_extractor *e, int mask) { if (!e) return ORBHIP_E_ARG; e->stage_mask = mask; return ORBHIP_OK; }
 int orbhip_dev_set_octree_threads(orbhip_extractor *e, int t) { if (!e) return ORBHIP_E_ARG; e->octree_threads = t; return ORBHIP_OK; }
 int orbhip_dev_set_fast_variant(orbhip_extractor *e, int v)
@@ -2637,6 +2424,7 @@ int orbhip_dev_fast_stamps(unsigned long long out[8])
     if (hipMemcpyToSymbol(HIP_SYMBOL(orbhip::g_fast_stamps), z, sizeof(z)) != hipSuccess) return ORBHIP_E_HIP;
     return ORBHIP_OK;
 }
+#endif
 
 int orbhip_extractor_set_profiling(orbhip_extractor *e, int on)
 {
@@ -2659,11 +2447,13 @@ int orbhip_extractor_stage_times(orbhip_extractor *e, float us[6])
     const long n = std::min<long>(e->prof_calls, orbhip_extractor::kProfRing);
     double acc[6] = {0, 0, 0, 0, 0, 0};
     // stage -> (begin, end) event of the set, all on the launch stream
-    static const int span[6][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {0, 5}};
+    // us[3] was the separate blur stage; the blur is fused into the descriptor kernel, nothing is launched (or timed) there
+    static const int span[6][2] = {{0, 1}, {1, 2}, {2, 3}, {-1, -1}, {3, 4}, {0, 4}};
     for (long c = 0; c < n; ++c) {
         hipEvent_t *ev = &e->ev[(size_t)c * orbhip_extractor::kProfEv];
         for (int i = 0; i < 6; ++i) {
             float ms = 0;
+            if (span[i][0] < 0) continue;
             ORBHIP_HIP_CHECK(hipEventElapsedTime(&ms, ev[span[i][0]], ev[span[i][1]]));
             acc[i] += ms * 1000.0;
         }

@@ -27,7 +27,7 @@ static_assert(sizeof(FastCell) == 32, "FastCell is one s_load_dwordx8");
 struct FastParams {
     uint32_t frame_bytes, rcp_cells;
     int ncells_total, slot_cap, ini_th, min_th, img_words, score_words;
-    int dev;   // development switch (timing floors)
+    int dev;   // development builds only: timing floors / stamped kernel
 };
 // the 749 disc offsets of IC_Angle, zero padded to 12 x 64 (pixel k of lane l = entry k*64 + l): signed (u, v) and the
 // int16 pairs (pixel 2k | pixel 2k+1 << 16) the moment dot products take
@@ -64,9 +64,9 @@ struct orbhip_extractor {
     hipStream_t stream = nullptr;       // stream every launch of this handle goes to
     hipStream_t own_stream = nullptr;   // created with the handle; `stream` may be re-pointed
     // profiling: ring of event sets (kProfEv events per extract call), averaged on read-out
-    static constexpr int kProfEv = 6;
+    static constexpr int kProfEv = 5;   // before the pyramid, after pyramid / FAST / octree / descriptors
     static constexpr int kProfRing = 256;
-    std::vector<hipEvent_t> ev;         // kProfRing * 6, created lazily
+    std::vector<hipEvent_t> ev;         // kProfRing * kProfEv, created lazily
     bool profiling = false;
     long prof_calls = 0;
 
@@ -79,8 +79,10 @@ struct orbhip_extractor {
     int octree_threads = 256;   // workgroup size of k_octree (256 / 512 / 1024)
     orbhip::FastLds fast_lds;   // k_fast_cells dynamic LDS carve-up
     int fast_lds_bytes = 0;
-    int stage_mask = 31;        // development switch (tools/coexec.py): stages launch_pipeline runs
-    int fast_variant = 0;       // development switch (tools/fast_ab.py): 2 stamped build, 3 / 4 timing floors
+#ifdef ORBHIP_DEVTOOLS
+    int stage_mask = 31;        // development build (tools/coexec.py): stages launch_pipeline runs
+    int fast_variant = 0;       // development build (tools/fast_ab.py): 2 stamped build, 3 / 4 timing floors
+#endif
     orbhip::CellDesc *d_cells = nullptr;
     std::vector<orbhip::FastCell> cells2;
     orbhip::FastCell *d_cells2 = nullptr;

@@ -970,7 +970,9 @@ __device__ __forceinline__ void resolve_par_carve(ResolveParState &S, unsigned c
     S.t_oct = c; c += n; S.taken = c; c += n; S.q_obs = c; c += nq; S.evbin = c;
 }
 
-__device__ unsigned int g_resolve_stats[4];   // development: {launched workgroups, sum of rounds, max rounds, -}
+#ifdef ORBHIP_DEVTOOLS
+__device__ unsigned int g_resolve_stats[4];   // development builds: {launched workgroups, sum of rounds, max rounds, -}
+#endif
 template <bool GS>
 __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, const orbhip_query *__restrict__ q, int nq,
                                                       const unsigned long long *__restrict__ cand,
@@ -1149,7 +1151,9 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
         for (int i = tid; i < nq; i += T) unobs |= !S.q_obs[i];
         if (__any(unobs))
             for (int i = tid; i < nq; i += T) if (!S.q_obs[i]) step(i);
+#ifdef ORBHIP_DEVTOOLS
         if (tid == 0) { atomicAdd(&g_resolve_stats[0], 1u); atomicAdd(&g_resolve_stats[1], (unsigned)rounds + 1); atomicMax(&g_resolve_stats[2], (unsigned)rounds + 1); }
+#endif
     } else {
         // mode 1 (map points: second candidate, ratio test among candidates of the same level).  Here a query CAN have
         // to give a held slot up: when its second candidate is taken by a smaller query, the next one may sit on the best
@@ -1173,7 +1177,9 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
             { int *t_ = own_cur; own_cur = own_nxt; own_nxt = t_; }
             __syncthreads();
             if (!changed) {
+#ifdef ORBHIP_DEVTOOLS
                 if (tid == 0) { atomicAdd(&g_resolve_stats[0], 1u); atomicAdd(&g_resolve_stats[1], (unsigned)round + 1); atomicMax(&g_resolve_stats[2], (unsigned)round + 1); }
+#endif
                 break;
             }
         }
@@ -2340,9 +2346,8 @@ static void launch_resolve_init(orbhip_matcher *m, int pairs, const DevFrame &D,
                                 int nq, int n_train, const unsigned long long *d_cand, const unsigned long long *d_ccand,
                                 const int *d_cnt, int stride, float nnratio, int check_ori, int *d_out, int *d_out_n, const Batch &B)
 {
-    static const bool dev_serial = getenv("ORBHIP_INIT_SERIAL") != nullptr;   // development switch: the serial replay
     const size_t bare = init_state_bytes((size_t)n_train, (size_t)nq, 0);
-    if (!dev_serial && n_train <= kResolveMax && nq <= kResolveMax && bare <= (size_t)kResolveLdsBudget) {
+    if (n_train <= kResolveMax && nq <= kResolveMax && bare <= (size_t)kResolveLdsBudget) {
         const int lcn = init_state_bytes((size_t)n_train, (size_t)nq, kResolveHead) <= (size_t)kResolveLdsBudget ? kResolveHead : 0;
         hipLaunchKernelGGL(k_resolve_init, dim3(pairs), dim3(1024), init_state_bytes((size_t)n_train, (size_t)nq, (size_t)lcn), m->stream,
                            D, d_qkeys, nq, d_cand, d_ccand, d_cnt, stride, nnratio, check_ori, d_out, d_out_n, B, n_train, nq, lcn);
@@ -2359,8 +2364,7 @@ static int launch_resolve_par(orbhip_matcher *m, int pairs, int mode, const DevF
                               const uint8_t *d_taken, float nnratio, int check_ori, int *d_out, int *d_out_n, const Batch &B,
                               int th_accept, int all_block)
 {
-    static const int dev_threads = getenv("ORBHIP_RESOLVE_THREADS") ? atoi(getenv("ORBHIP_RESOLVE_THREADS")) : 0;
-    const int threads = dev_threads ? dev_threads : 1024;
+    const int threads = 1024;
     if (n_train <= kResolveMax && nq <= kResolveMax) {
         // LDS state sized by the batch's capacities; the list heads go to LDS when the budget allows
         const size_t state = resolve_par_bytes((size_t)n_train, (size_t)nq, 0);
@@ -3256,14 +3260,15 @@ int orbhip_track_last_frame_device(orbhip_matcher *m, int pairs, const orbhip_ca
                                    int check_ori, void *d_assign, void *d_nmatches)
 {
     if (!m || !cam || pairs <= 0 || cap <= 0 || !d_desc) return ORBHIP_E_ARG;
+    if (!d_Tcw || !d_Tlw || !d_kps || !d_n || !d_world || !d_flags || cam->n_levels < 1 || cam->n_levels > ORBHIP_MAX_LEVELS)
+        return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(m->device));   // before scratch(): its buffers must land on the matcher's device
     int rc;
     void *p;
     if ((rc = scratch(m, S_Q, (size_t)pairs * cap * sizeof(orbhip_query), &p))) return rc;
     orbhip_query *d_q = (orbhip_query *)p;
     if ((rc = scratch(m, S_TAKEN, (size_t)pairs * sizeof(int), &p))) return rc;   // per-pair query counts
     int *d_nq = (int *)p;
-    if (!d_Tcw || !d_Tlw || !d_kps || !d_n || !d_world || !d_flags || cam->n_levels < 1 || cam->n_levels > ORBHIP_MAX_LEVELS)
-        return ORBHIP_E_ARG;
     ProjLaunch proj;
     proj.P = {(const float *)d_Tcw, (const float *)d_Tlw, (const orbhip_keypoint *)d_kps, (const int *)d_n,
               (const float *)d_world, (const uint8_t *)d_flags, d_q, d_nq, 0, cap, last_first, last_step};
@@ -3345,7 +3350,8 @@ int orbhip_frustum_queries(orbhip_matcher *m, const orbhip_camera *cam, const fl
     return ORBHIP_OK;
 }
 
-// development: {workgroups, sum of rounds, max rounds} of the parallel resolve since the last call
+#ifdef ORBHIP_DEVTOOLS
+// development builds: {workgroups, sum of rounds, max rounds} of the parallel resolve since the last call
 int orbhip_dev_resolve_stats(unsigned int out[4])
 {
     unsigned int z[4] = {0, 0, 0, 0};
@@ -3353,6 +3359,7 @@ int orbhip_dev_resolve_stats(unsigned int out[4])
     if (hipMemcpyToSymbol(HIP_SYMBOL(orbhip::g_resolve_stats), z, sizeof(z)) != hipSuccess) return ORBHIP_E_HIP;
     return ORBHIP_OK;
 }
+#endif
 
 int orbhip_keyframe_queries(orbhip_matcher *m, const orbhip_camera *cam, int mode, int double_invz, const float *T1,
                             const float *T2, int n, const float *world, const float *normal, const float *max_dist,

@@ -417,3 +417,56 @@ def test_large_host_batch_runs_as_a_chunk_pipeline(mods):
     assert np.array_equal(small[2][1], res[2][1])
     again = ext.extract_batch(frames[:33])
     assert np.array_equal(again[32][1], res[32][1])
+
+
+def test_stage_accessors_follow_every_extraction_of_a_reused_handle(mods):
+    """mvImagePyramid / the blurred planes / the FAST candidates belong to the LAST extraction of a handle, also when
+    that extraction was a hipGraph replay (same shape, batch and capacity as the previous call) and the blurred planes
+    of the previous image had been produced on request in between (they are cached behind a validity flag)."""
+    pkg, O = mods
+    ext = pkg.ORBextractor(500, 1.2, 6, 20, 7)
+    ora = O.OracleExtractor(500, 1.2, 6, 20, 7)
+    imgs = [synth_frame(70 + s, 480, 320) for s in range(3)]
+    for it, img in enumerate(imgs + imgs[:1]):          # capture, replay, replay, replay
+        kps, desc = ext(img)
+        okps, odesc = ora.extract(img)
+        assert_kps_equal(kps, okps, "call %d" % it)
+        assert np.array_equal(desc, odesc)
+        assert_stagewise_equal(ext, ora, 6, "call %d" % it)   # downloads pyramid, candidates and blurred planes
+    # the same through the device-pointer entry (plain launches) and the batch entry
+    res = ext.extract_batch(np.stack(imgs))
+    ora.extract(imgs[0])
+    for l in range(6):
+        if ora.level_blurred(l) is not None:
+            assert np.array_equal(ext.blurred_level(l, frame=0), ora.level_blurred(l))
+    assert np.array_equal(res[0][1], O.OracleExtractor(500, 1.2, 6, 20, 7).extract(imgs[0])[1])
+
+
+def test_page_locked_strided_source_is_read_in_place(mods):
+    """Host batches >= 32 frames whose images sit in page-locked memory skip the staging copy: every frame travels as one
+    1-D copy of its rows in the caller's row stride (no rectangle copy anywhere) and the kernels read that layout."""
+    import torch
+    pkg, O = mods
+    from orb_slam2_comment_amd.capi import KP_DTYPE, check, lib
+    import ctypes as C
+    Wd, Hd, stride, fstride, B = 400, 300, 448, 448 * 300 + 1024, 33
+    pin = torch.zeros(B * fstride, dtype=torch.uint8).pin_memory()
+    host = pin.numpy()
+    host[:] = 0xA5                                                  # the gaps must not leak into any level
+    uniq = [synth_frame(80 + s, Wd, Hd) for s in range(4)]
+    for b in range(B):
+        v = host[b * fstride: b * fstride + Hd * stride].reshape(Hd, stride)
+        v[:, :Wd] = uniq[b % 4]
+    ext = pkg.ORBextractor(600, 1.2, 7, 20, 7)
+    cap = ext.capacity(Hd, Wd)
+    kps = np.zeros((B, cap), KP_DTYPE); desc = np.zeros((B, cap, 32), np.uint8); n = np.zeros(B, np.int32)
+    check(lib().orbhip_extract_batch(ext._h, C.c_void_p(pin.data_ptr()), B, Hd, Wd, stride, fstride,
+                                     kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap,
+                                     n.ctypes.data_as(C.c_void_p)), "orbhip_extract_batch")
+    ora = O.OracleExtractor(600, 1.2, 7, 20, 7)
+    for s in range(4):
+        okps, odesc = ora.extract(uniq[s])
+        for b in range(s, B, 4):
+            assert_kps_equal(kps[b, :n[b]], okps, "frame %d" % b)
+            assert np.array_equal(desc[b, :n[b]], odesc)
+        assert np.array_equal(ext.image_pyramid(0, frame=s + 28, with_border=True), ora.level_padded(0))

@@ -3,7 +3,7 @@
 matcher each, own stream); every stage X of pipeline A is repeated alone, every stage Y of pipeline B alone, then
 both loops run concurrently.  overlap = (t_X + t_Y) / t_both: 1.0 = the two stages just take turns, 2.0 = they fit
 beside each other for free.  Stages: P pyramid, F FAST, O octree, B blur, D orientation + descriptors, M matching
-(TrackLastFrameDevice).  Uses the development switch orbhip_dev_set_stage_mask; never part of the product API.
+(TrackLastFrameDevice).  Uses orbhip_dev_set_stage_mask of the -DORBHIP_DEVTOOLS build (tools/_dev/liborbhip_dev.so); the product library has no such export.
 
   python tools/coexec.py [--frames 64] [--reps 20]
 """
@@ -21,12 +21,22 @@ sys.path.insert(0, ROOT)
 STAGES = {"P": 1, "F": 2, "O": 4, "B": 8, "D": 16}
 
 
+def use_dev_build():
+    """These tools drive development exports (orbhip_dev_*) that only the -DORBHIP_DEVTOOLS build of the library has:
+    `make -C orb_slam2_comment_amd/csrc dev` writes it to tools/_dev/liborbhip_dev.so; the product library is untouched."""
+    import subprocess
+    from orb_slam2_comment_amd import capi
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "orb_slam2_comment_amd", "csrc"), "dev"], check=True)
+    capi.use_library(os.path.join(ROOT, "tools", "_dev", "liborbhip_dev.so"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--groups", default="P,F,O,B,D,M", help="comma-separated stage groups, e.g. PB,F,ODM")
     args = ap.parse_args()
+    use_dev_build()
     import torch
     from orb_slam2_comment_amd import ORBextractor, ORBmatcher
     from orb_slam2_comment_amd import matcher as M

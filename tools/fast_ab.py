@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development tool: per-stage HIP-event times of one 64-frame pipeline for kernel variants, interleaved
 rounds in ONE process (cdna_hip_programming.md section 5.4 rule 24).  Variants are the development switches
-exported by liborbhip.so (orbhip_dev_*), never part of the product API.
+exported only by the -DORBHIP_DEVTOOLS build (tools/_dev/liborbhip_dev.so, orbhip_dev_*), never part of the product library.
 
   python tools/fast_ab.py [--rounds 8] [--frames 64] [--variants 1,0]
 """
@@ -17,6 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def use_dev_build():
+    """These tools drive development exports (orbhip_dev_*) that only the -DORBHIP_DEVTOOLS build of the library has:
+    `make -C orb_slam2_comment_amd/csrc dev` writes it to tools/_dev/liborbhip_dev.so; the product library is untouched."""
+    import subprocess
+    from orb_slam2_comment_amd import capi
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "orb_slam2_comment_amd", "csrc"), "dev"], check=True)
+    capi.use_library(os.path.join(ROOT, "tools", "_dev", "liborbhip_dev.so"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=8)
@@ -27,6 +36,7 @@ def main():
     ap.add_argument("--size", default="1241x376")
     ap.add_argument("--nfeatures", type=int, default=1000)
     args = ap.parse_args()
+    use_dev_build()
     import torch
     from orb_slam2_comment_amd import ORBextractor
     from orb_slam2_comment_amd.capi import lib
