@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: frames/s of the ORB front-end + frame-to-frame matching on synthetic KITTI-shape frames.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-gpu B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--global-batch 512 | --frames-per-gpu B]
 
 Headline workload (BASELINE.json metric "ORB extract+match, KITTI 1241x376 @1000 feat"; configs[1] + the
-SearchByProjection half of configs[2]): B synthetic 1241x376 uint8 frames per GPU already resident in HBM, as B/2
-(LastFrame, CurrentFrame) pairs.  One "step" = ORBextractor::operator() over the B frames (nFeatures=1000,
+SearchByProjection half of configs[2]): a global batch of 512 synthetic 1241x376 uint8 frames (BASELINE.json configs[3]:
+"batch=512 ... sharded one-per-GPU"), B = 512 / N of them per GPU, already resident in HBM as B/2 (LastFrame, CurrentFrame)
+pairs.  One "step" = ORBextractor::operator() over the B frames (nFeatures=1000,
 scaleFactor 1.2, 8 levels, iniThFAST 20 / minThFAST 7) + ORBmatcher::SearchByProjection(CurrentFrame, LastFrame,
 th=15, bMono) for the B/2 pairs (src/Tracking.cc:880-885), projection prologue included, everything device resident.
 `value` = frames through that step per second.
@@ -14,8 +15,8 @@ For N > 1 the driver launches one rank per GPU with torch.distributed.run; `pyth
 environment spawns the N ranks itself (before anything touches a GPU).  Pair p of the global batch goes to rank
 p mod N; every step ends with the RCCL gather of the fixed-capacity result slots to rank 0 (configs[3]).
 
-Named secondary objects in the same JSON line (never `value`): extract_only (configs[1]), stereo (configs[2]:
-extract L+R + Frame::ComputeStereoMatches), euroc_init (configs[4]: 752x480 @2000 + SearchForInitialization),
+Named secondary objects in the same JSON line (never `value`): extract_only (configs[1]), stereo (configs[2] as one leg:
+extract L+R on two handles + Frame::ComputeStereoMatches + SearchByProjection at th = 7 with the `ur` gate), euroc_init (configs[4]: 752x480 @2000 + SearchForInitialization),
 bow (extract + ComputeBoW + SearchByBoW).  Rank 0 prints ONE JSON line; README/DESIGN.md describe `roofline` and
 `cpu_baseline`.
 """
@@ -37,19 +38,24 @@ LEVEL_PX = [1241 * 376, 1034 * 313, 862 * 261, 718 * 218, 598 * 181, 499 * 151, 
 SUM_P = sum(LEVEL_PX)                                   # 1,444,097 px
 # algorithmic bytes per frame of each stage (stage-materialised model)
 ALGO_BYTES = {
-    "pyramid": LEVEL_PX[0] + (SUM_P - LEVEL_PX[7]) + SUM_P,   # K1: reads P0 + (SumP-P7), writes SumP
+    "pyramid": (SUM_P - LEVEL_PX[7]) + (SUM_P - LEVEL_PX[0]),  # K1 as executed by the headline's monocular handles (lazy
+                                                              # mvImagePyramid[0]): reads SumP-P7, writes SumP-P0; with the
+                                                              # level-0 copy it is P0 + (SumP-P7) + SumP (ALGO_PYRAMID_FULL)
     "fast": SUM_P,                                            # K2+K3: reads SumP
     "blur": 0,                                                # K6 is fused into the descriptor kernel (no blurred plane)
-    "describe": NFEAT * (43 * 43) + NFEAT * 60,               # K5+K6+K7: the 43 x 43 window a keypoint's moments and
-                                                              # blurred 37 x 37 patch depend on + 60 B out per keypoint
+    "describe": NFEAT * (749 + 512) + NFEAT * 60,             # K5+K7 of SURVEY 8d: N*(749+512) read + N*(32+28) written; K6's
+                                                              # 2*SumP is NOT counted: no blurred plane is written or read
     "octree": 0,
 }
-KERNEL_NAME = {"pyramid": "k_pyr_base+k_pyr_rows(x6)", "fast": "k_fast_cells", "blur": "(fused into k_describe_fused)",
+ALGO_PYRAMID_FULL = LEVEL_PX[0] + (SUM_P - LEVEL_PX[7]) + SUM_P
+KERNEL_NAME = {"pyramid": "k_pyr_base(level 1)+k_pyr_rows(x6)", "fast": "k_fast_cells", "blur": "(fused into k_describe_fused)",
                "describe": "k_describe_fused", "octree": "k_octree"}
 FRAME_BYTES_MODEL = 8971771                             # BASELINE.md section 3, whole path
 HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, KITTI_BF = 718.856, 718.856, 607.1928, 185.2157, 386.1448   # KITTI00-02.yaml
 TRACK_TH, DEPTH = 15.0, 12.0                            # src/Tracking.cc:880 (mono th = 15); synthetic scene depth [m]
+STEREO_TH = 7.0                                         # src/Tracking.cc:882-885 (stereo th = 7)
+GLOBAL_BATCH = 512                                      # BASELINE.json configs[3]
 MIN_TIMED_S = 1.0                                       # the timed region of every leg lasts at least this long
 
 
@@ -204,11 +210,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-gpu", type=int, default=128,
-                    help="frames resident in HBM per GPU and step (split over --handles pipelines: 44 + 42 + 42 by default)")
+    ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH,
+                    help="frames per step over all GPUs (BASELINE.json configs[3]: 512); every GPU gets global/N of them, "
+                         "split over --handles pipelines")
+    ap.add_argument("--frames-per-gpu", type=int, default=None,
+                    help="fix the frames per GPU and step instead (weak scaling: the global batch grows with N)")
     ap.add_argument("--min-time", type=float, default=MIN_TIMED_S,
                     help="minimum length in seconds of every timed region (profiler runs pass 0: one repeat of --steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace-run", action="store_true",
+                    help="for kernel-trace tools: warm-up + K plain steps of the headline (no HIP events between the stages, no "
+                         "secondary legs), one short JSON line")
     ap.add_argument("--no-secondary", "--no-match", dest="no_secondary", action="store_true",
                     help="skip the secondary legs (extract-only, stereo, EuRoC initialisation, BoW)")
     ap.add_argument("--dist-backend", default="nccl",
@@ -270,279 +282,125 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from orb_slam2_comment_amd.sharding import gather_into, gather_to_rank0, shard_indices
-    B = args.frames_per_gpu
-    assert B % 2 == 0 and B >= 2, "--frames-per-gpu must be even: frames come as (last, cur) pairs"
-    pairs_local = B // 2
-    my_pairs = shard_indices(pairs_local * world, rank, world)          # global pair p -> rank p mod N
+    if args.frames_per_gpu is not None:
+        B, scaling = args.frames_per_gpu, "weak"          # per-GPU work fixed, the global batch grows with N
+    else:
+        B, scaling = (args.global_batch // world) & ~1, "strong"   # total work fixed (configs[3]: 512 frames over N GPUs)
+    assert B % 2 == 0 and B >= 2, "frames per GPU must be even and >= 2: frames come as (last, cur) pairs"
 
     if args.dry_run:
-        return dry_run(args, dist, torch, world, rank, multi, my_pairs, gather_to_rank0)
+        return dry_run(args, dist, torch, world, rank, multi, shard_indices((B // 2) * world, rank, world), gather_to_rank0, B)
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    from orb_slam2_comment_amd import ORBextractor, ORBmatcher
-    from orb_slam2_comment_amd import matcher as M
-    from orb_slam2_comment_amd.capi import POINT_OBSERVED, POINT_PRESENT
-    from orb_slam2_comment_amd.synth import synth_frame
-
-    # local frames: pair k = (scene s, scene s translated by 3 px): 8 scenes -> 16 distinct images per rank
-    uniq = {}
-    for li in range(B):
-        key = (1 + (li // 2) % 8, li % 2)
-        if key not in uniq:
-            uniq[key] = synth_frame(key[0], W, H, shift_xy=(3 * key[1], 0))
-    frames = np.stack([uniq[(1 + (li // 2) % 8, li % 2)] for li in range(B)])
-    d_img = torch.from_numpy(frames).to(dev)
-
-    Hn = max(1, min(args.handles, pairs_local))
-    psplit = [pairs_local // Hn + (1 if h < pairs_local % Hn else 0) for h in range(Hn)]     # pairs per pipeline
-    splits = [2 * p for p in psplit]
-    offs = [sum(splits[:h]) for h in range(Hn)]
-    Bh = splits[0]
-    exts, mts, streams = [], [], []
-    for h in range(Hn):
-        e = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
-        mt = ORBmatcher(0.9, True, device=local_rank)
-        st = torch.cuda.Stream(dev)              # one real (non-null) stream per pipeline: a null handle would mean
-        e.set_stream(st.cuda_stream)             # "the handle's own stream", and extractor and matcher must share one
-        mt.set_stream(st.cuda_stream)
-        exts.append(e); mts.append(mt); streams.append(st)
-    ext = exts[0]
-    cap = ext.capacity(H, W)
-    sf = ext.GetScaleFactors()
-    cam = M.make_camera(KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, (0.0, 0.0, float(W), float(H)), sf, mbf=KITTI_BF,
-                        mb=KITTI_BF / KITTI_FX)
-    # one flat allocation per output set: {KeyPoint[B][cap] | desc[B][cap][32] | count[B] | assign[B/2][cap] |
-    # nmatches[B/2]} are views of it, so the multi-GPU exchange is ONE gather of one contiguous buffer per step
-    nb_k, nb_d, nb_a = B * cap * 28, B * cap * 32, pairs_local * cap * 4
-    off_d = (nb_k + 255) & ~255                      # every view starts 256-byte aligned
-    off_n = (off_d + nb_d + 255) & ~255
-    off_a = (off_n + B * 4 + 255) & ~255
-    off_m = (off_a + nb_a + 255) & ~255
-    flat_bytes = off_m + pairs_local * 4
-
-    def out_set():
-        flat = torch.zeros(flat_bytes, dtype=torch.uint8, device=dev)
-        return {"k": flat[:nb_k].view(torch.int32).view(B, cap, 7), "d": flat[off_d:off_d + nb_d].view(B, cap, 32),
-                "n": flat[off_n:off_n + B * 4].view(torch.int32), "a": flat[off_a:off_a + nb_a].view(torch.int32).view(pairs_local, cap),
-                "m": flat[off_m:off_m + pairs_local * 4].view(torch.int32), "st": torch.zeros(B, dtype=torch.int32, device=dev),
-                "flat": flat}
-
-    # the synthetic map: every last-frame keypoint carries a map point at depth DEPTH in the last camera's frame
-    # (Tlw = I); the current camera is translated so that such a point moves by 3 px -- the shift between the two
-    # rendered views.  World positions are rebuilt from the keypoints of each extraction ON THE DEVICE by a tiny
-    # torch expression (input synthesis for the benchmark, the stand-in for the map that Tracking would hold).
-    Tlw = torch.eye(4, dtype=torch.float32)[:3, :].reshape(1, 12).repeat(pairs_local, 1).contiguous().to(dev)
-    Tc = torch.eye(4, dtype=torch.float32)
-    Tc[0, 3] = float(np.float32(3.0) * np.float32(DEPTH) / np.float32(KITTI_FX))
-    Tcw = Tc[:3, :].reshape(1, 12).repeat(pairs_local, 1).contiguous().to(dev)
-    d_world = torch.zeros((B, cap, 3), dtype=torch.float32, device=dev)
-    d_flags = torch.full((B, cap), POINT_PRESENT | POINT_OBSERVED, dtype=torch.uint8, device=dev)
-
-    def build_map(o):
-        kf = o["k"][0::2].view(torch.float32)                       # last frames of the pairs
-        z = float(DEPTH)
-        d_world[0::2, :, 0] = (kf[..., 0] - KITTI_CX) * (z / KITTI_FX)
-        d_world[0::2, :, 1] = (kf[..., 1] - KITTI_CY) * (z / KITTI_FY)
-        d_world[0::2, :, 2] = z
-
-    obuf = [out_set()]
-    nbuf = args.out_buffers if multi and not rehearsal else 1
-    for _ in range(nbuf - 1):
-        obuf.append(out_set())
-    gstream = torch.cuda.Stream(dev) if nbuf >= 2 else None
-    gdone = [None] * nbuf
-    gout = None
-    if nbuf >= 2 and rank == 0:
-        gout = [torch.zeros((world, flat_bytes), dtype=torch.uint8, device=dev)]   # rank-major, same carve-up per rank
-    stepno = [0]
-    # torch events around the matching of pipeline 0 (recorded on the stream its launches go to): a ring of 256 pairs
-    match_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(256)] for _ in range(2)]
-    record_match = [False]
-    match_calls = [0]
-
-    def extract_all(o, which=None):
-        for h, e in enumerate(exts):
-            if which is not None and h != which:
-                continue
-            sl = slice(offs[h], offs[h] + splits[h])
-            e.extract_batch_device(d_img[sl].data_ptr(), splits[h], H, W, o["k"][sl].data_ptr(), o["d"][sl].data_ptr(),
-                                   cap, o["n"][sl].data_ptr(), o["st"][sl].data_ptr())
-
-    def match_all(o):
-        for h, mt in enumerate(mts):
-            f0, p0 = offs[h], offs[h] // 2
-            if record_match[0] and h == 0:
-                match_ev[0][match_calls[0] % 256].record(streams[0])
-            # pair j of this pipeline: LastFrame = frame f0 + 2j, CurrentFrame = f0 + 2j + 1 of the shared arrays
-            mt.TrackLastFrameDevice(psplit[h], cam, Tcw[p0:].data_ptr(), Tlw[p0:].data_ptr(), o["k"].data_ptr(),
-                                    o["d"].data_ptr(), o["n"].data_ptr(), cap, f0 + 1, 2, f0, 2, d_world.data_ptr(),
-                                    d_flags.data_ptr(), TRACK_TH, True, o["a"][p0:].data_ptr(), o["m"][p0:].data_ptr())
-            if record_match[0] and h == 0:
-                match_ev[1][match_calls[0] % 256].record(streams[0])
-                match_calls[0] += 1
-
-    def step():
-        k = stepno[0] % nbuf
-        stepno[0] += 1
-        o = obuf[k]
-        if gdone[k] is not None:                 # the gather that last read this buffer must be finished
-            for st in streams:
-                st.wait_event(gdone[k])
-        extract_all(o)
-        match_all(o)
-        if multi:
-            if rehearsal:
-                torch.cuda.synchronize(dev)
-                return gather_to_rank0(o["k"].cpu(), o["d"].cpu(), o["n"].cpu())
-            for st in streams:
-                gstream.wait_stream(st)
-            with torch.cuda.stream(gstream):
-                out = gather_into(gout, (o["flat"],))
-                gdone[k] = gstream.record_event()
-            return out
-        return None
-
-    def barrier():
-        torch.cuda.synchronize(dev)              # drains the pipeline streams and the gather stream
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    def allreduce_max(v):
-        if not multi:
-            return v
-        t = torch.tensor([v], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    # the map of every output set is built once from a first extraction (keypoints are deterministic per image)
-    for o in obuf:
-        extract_all(o)
-        torch.cuda.synchronize(dev)
-        build_map(o)
-    torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # ---- the measurement the contract asks for: EXACTLY K steps between barriers -> ms_per_step, value ----------
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt_k = allreduce_max(time.perf_counter() - t0)
-    # ---- the same steps again, R x K of them (>= 1 s), with the per-stage HIP events on: stage_us / roofline -----
-    for e in exts:
-        e.set_profiling(True)                   # HIP events around every stage, on the launch stream
-    record_match[0] = True
-    reps = max(1, int(np.ceil(args.min_time / max(dt_k, 1e-6))))
-    reps = int(allreduce_max(float(reps)))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(reps * args.steps):
-        step()
-    barrier()
-    dt_long = allreduce_max(time.perf_counter() - t0)
-    record_match[0] = False
-    stages = [e.stage_times_us() for e in exts]
-    stage = {k: sum(st[k] for st in stages) / len(stages) for k in stages[0]}
-    for e in exts:
-        e.set_profiling(False)
-    nev = min(match_calls[0], 256)
-    stage["match"] = float(np.mean([match_ev[0][i].elapsed_time(match_ev[1][i]) for i in range(nev)])) * 1e3 if nev else 0.0
-    o = obuf[0]
-    n_host, nm_host = o["n"].cpu().numpy(), o["m"].cpu().numpy()
-    assert int(o["st"].abs().sum().item()) == 0 and n_host.min() > 0, "extraction failed"
-    assert nm_host.min() > 100, "SearchByProjection found too few matches: the synthetic pairs are broken"
-
-    # pipeline 0 once more, ALONE on the GPU (the other pipelines idle): the stand-alone launch times of its kernels, which
-    # is what rocprofv3 shows for a single-pipeline run; reported beside the contended times of the timed region above
-    torch.cuda.synchronize(dev)
-    exts[0].set_profiling(True)
-    for _ in range(40):
-        extract_all(obuf[0], which=0)
-    torch.cuda.synchronize(dev)
-    stage_alone = exts[0].stage_times_us()
-    exts[0].set_profiling(False)
-
+    ctx = {"args": args, "torch": torch, "dist": dist, "dev": dev, "world": world, "rank": rank, "local_rank": local_rank,
+           "multi": multi, "rehearsal": rehearsal, "gather_into": gather_into, "gather_to_rank0": gather_to_rank0}
+    head = Headline(ctx, B)
+    if args.trace_run:
+        res = head.measure(stages=False)
+        if rank == 0:
+            emit_json({"metric": "trace run (headline steps only)", "value": round(res["fps"], 1), "unit": "frames/s", "n_gpus": world,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res["dt_long"] / res["steps_long"] * 1e3, 4)})
+        return
+    res = head.measure()
     if rank == 0:
-        print("[bench] headline done: %.1f frames/s; secondary legs ..." % (B * world * reps * args.steps / dt_long), file=sys.stderr, flush=True)
+        print("[bench] headline done: %.1f frames/s; secondary legs ..." % res["fps"], file=sys.stderr, flush=True)
     secondary = None
     if not args.no_secondary and world == 1 and not multi:
-        secondary = secondary_legs(args, torch, dev, local_rank, exts, streams, obuf[0], d_img, cap, splits, offs, psplit, extract_all)
+        secondary = secondary_legs(args, torch, dev, local_rank, head)
+    weak = None
+    if world > 1 and scaling == "strong" and not args.no_secondary:
+        # the round-2 workload beside it: 128 frames per GPU whatever N is (weak scaling), never `value`
+        head.close()
+        w = Headline(ctx, 128)
+        wr = w.measure(stages=False)
+        weak = {"value": round(wr["fps"], 1), "unit": "frames/s", "scaling": "weak",
+                "what": "the same step with 128 frames per GPU (global batch %d)" % (128 * world),
+                "ms_per_step": round(wr["dt_long"] / wr["steps_long"] * 1e3, 4), "timed_s": round(wr["dt_long"], 4)}
+        w.close()
 
     if rank == 0:
-        steps_long = reps * args.steps
-        fps = B * world * steps_long / dt_long                  # the >= 1 s region; `value`
+        stage, stage_alone, Bm = res["stage"], res["stage_alone"], res["frames_per_launch"]
+        fps, steps_long, dt_long, dt_k, reps = res["fps"], res["steps_long"], res["dt_long"], res["dt_k"], res["reps"]
         fps_k = B * world * args.steps / dt_k                   # exactly K steps
-        # dominant single kernel: largest HIP-event time among the one-launch stages (the pyramid stage is 8
-        # dependent launches, the matching 4 small ones)
+        # dominant single kernel: largest HIP-event time among the one-launch stages (the pyramid stage is 7
+        # dependent launches, the matching 3 small ones)
         kern = max(("fast", "describe"), key=lambda k: stage[k])
         if stage["fast"] >= 0.8 * stage[kern]:
             kern = "fast"     # rocprofv3 --stats: k_fast_cells has the largest total time of any single kernel; with several
                               # pipelines interleaved the other kernels are stretched more than the VALU-bound FAST
-        algo = ALGO_BYTES[kern] * Bh                # frames per launch of one handle
+        # frames per launch: the pipelines get 172 / 170 / 170 frames of a 512-frame step; stage times are means over
+        # the pipelines, so the bytes are those of the MEAN launch
+        algo = ALGO_BYTES[kern] * Bm
         achieved = algo / (stage[kern] * 1e-6) / 1e9
         traffic, valu = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 pm = json.load(open(tpath))[kern]
-                traffic = round(pm["hbm_bytes_per_frame"] * Bh)
+                traffic = round(pm["hbm_bytes_per_frame"] * Bm)
                 if "valu_issue_us_per_frame" in pm:
-                    # the kernel is priced against HBM as the contract asks, but what bounds it is VALU issue:
-                    # PMC instruction count x 4 cycles / (1024 SIMDs x 2.4 GHz) against the measured launch time
-                    vi = pm["valu_issue_us_per_frame"] * Bh
-                    valu = {"insts_per_launch": pm["valu_insts_per_frame"] * Bh, "issue_us_per_launch": round(vi, 1),
-                            "frac_of_launch": round(vi / stage[kern], 3)}
+                    # the kernel is priced against HBM as the contract asks, but what bounds it is VALU issue: PMC
+                    # instruction count x the measured issue cost of its instruction mix (tools/micro)
+                    vi = pm["valu_issue_us_per_frame"] * Bm
+                    valu = {"insts_per_launch": pm["valu_insts_per_frame"] * Bm, "issue_us_per_launch": round(vi, 1),
+                            "frac_of_launch": round(vi / stage[kern], 3), "model": pm.get("valu_issue_model")}
             except Exception:
                 traffic, valu = None, None
         try:
             metric_name = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
             metric_name = "frames/sec ORB extract+match, KITTI 1241x376 @1000 feat; HBM GB/s vs peak"
+        other_denoms = {"pyramid": "SURVEY 8d K1 without the level-0 copy, which these monocular handles do not execute: (SumP - P7) read "
+                                   "+ (SumP - P0) written (the full K1 figure, P0 + (SumP - P7) + SumP, applies to the stereo leg)",
+                        "describe": "SURVEY 8d K5+K7: N*(749+512) read + N*60 written; K6's 2*SumP is not moved (the blur is fused) "
+                                    "and not counted"}
         out = {
             "metric": metric_name,
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt_long / steps_long * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "configs[1]+[2]: synthetic 1241x376 u8 frames resident in HBM as (last, cur) pairs; per step "
-                                   "ORB extract (nFeatures=1000, 8-level pyramid) of every frame + device-resident "
-                                   "SearchByProjection(CurrentFrame, LastFrame, th=15, mono; projection prologue included) "
-                                   "for every pair" +
-                                   ("; configs[3]: pairs round-robin over the GPUs + RCCL gather of the result slots to rank 0" if world > 1 else ""),
-                       "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": pairs_local, "handles_per_gpu": Hn,
-                       "frames_per_launch": Bh, "global_batch": B * world, "nfeatures": NFEAT,
-                       "levels": NLEVELS, "mean_keypoints_per_frame": round(float(n_host.mean()), 1),
-                       "mean_matches_per_pair": round(float(nm_host.mean()), 1),
+            "config": {"workload": "configs[1]+[2]+[3]: a global batch of %d synthetic 1241x376 u8 frames per step, %d per GPU, resident in "
+                                   "HBM as (last, cur) pairs; per step ORB extract (nFeatures=1000, 8-level pyramid) of every frame + "
+                                   "device-resident SearchByProjection(CurrentFrame, LastFrame, th=15, mono; projection prologue "
+                                   "included) for every pair; monocular handles: mvImagePyramid[0] on demand "
+                                   "(orbhip_extractor_set_lazy_level0), never asked for here" % (B * world, B) +
+                                   ("; pairs round-robin over the GPUs + RCCL gather of the result slots to rank 0" if world > 1 else ""),
+                       "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": B // 2, "handles_per_gpu": head.Hn,
+                       "frames_per_launch": head.splits, "mean_frames_per_launch": Bm, "global_batch": B * world, "nfeatures": NFEAT,
+                       "levels": NLEVELS, "mean_keypoints_per_frame": res["mean_kp"],
+                       "mean_matches_per_pair": res["mean_matches"],
                        "parallelism": "pair-sharded x%d" % world,
-                       "gather_bytes_per_rank_per_step": flat_bytes if multi else 0},
+                       "gather_bytes_per_rank_per_step": head.flat_bytes if multi else 0},
             "timing": {"timed_steps": steps_long, "timed_s": round(dt_long, 4), "timed_repeats_of_steps": reps,
                        "exactly_k_steps": {"steps": args.steps, "s": round(dt_k, 5), "ms_per_step": round(dt_k / args.steps * 1e3, 4),
                                            "frames_per_s": round(fps_k, 1)}},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAME[kern],
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "valu_issue": valu,
-                         "algorithmic_bytes_per_launch": algo,
+                         "algorithmic_bytes_per_launch": round(algo),
                          "avg_launch_us": round(stage[kern], 2),
-                         "alone": {"what": "the same launch (%d frames) with no other pipeline on the GPU" % Bh,
+                         "alone": {"what": "a launch of pipeline 0 (%d frames) with no other pipeline on the GPU" % head.splits[0],
                                    "avg_launch_us": round(stage_alone[kern], 2),
-                                   "achieved": round(algo / (stage_alone[kern] * 1e-6) / 1e9, 2),
-                                   "frac": round(algo / (stage_alone[kern] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+                                   "achieved": round(ALGO_BYTES[kern] * head.splits[0] / (stage_alone[kern] * 1e-6) / 1e9, 2),
+                                   "frac": round(ALGO_BYTES[kern] * head.splits[0] / (stage_alone[kern] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
                                    "stage_us": {k: round(v, 2) for k, v in stage_alone.items()}},
-                         "other_stages": {k: {"kernel": KERNEL_NAME[k], "algorithmic_bytes_per_launch": ALGO_BYTES[k] * Bh,
-                                              "frac": round(ALGO_BYTES[k] * Bh / (stage[k] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
-                                              "frac_alone": round(ALGO_BYTES[k] * Bh / (stage_alone[k] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)}
+                         "other_stages": {k: {"kernel": KERNEL_NAME[k], "algorithmic_bytes_per_launch": round(ALGO_BYTES[k] * Bm),
+                                              "denominator": other_denoms[k],
+                                              "frac": round(ALGO_BYTES[k] * Bm / (stage[k] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+                                              "frac_alone": round(ALGO_BYTES[k] * head.splits[0] / (stage_alone[k] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5)}
                                           for k in ("pyramid", "describe") if stage[k] > 0 and stage_alone[k] > 0},
                          "stage_us": {k: round(v, 2) for k, v in stage.items()},
                          "whole_path_GBps_model": round(FRAME_BYTES_MODEL * fps / world / 1e9, 2)},
         }
+        if weak:
+            out["weak_128_per_gpu"] = weak
         if secondary:
             out.update(secondary)
         if not args.no_cpu_baseline and world == 1:
             print("[bench] GPU legs done; cpu_baseline (~25 s) ...", file=sys.stderr, flush=True)
-            out["cpu_baseline"] = cpu_baseline(frames[:16])
+            out["cpu_baseline"] = cpu_baseline(head.frames[:16])
         else:
             out["cpu_baseline"] = None
         emit_json(out)
@@ -552,11 +410,232 @@ def main():
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def secondary_legs(args, torch, dev, local_rank, exts, streams, o, d_img, cap, splits, offs, psplit, extract_all):
+class Headline:
+    """The headline step for B frames per GPU: pipelines (extractor + matcher + stream each), resident frames, the
+    synthetic map, rotating output sets and, with several ranks, the gather of step k beside the work of step k+1."""
+
+    def __init__(self, ctx, B):
+        self.ctx, self.B = ctx, B
+        args, torch, dev, world = ctx["args"], ctx["torch"], ctx["dev"], ctx["world"]
+        local_rank, multi, rehearsal = ctx["local_rank"], ctx["multi"], ctx["rehearsal"]
+        from orb_slam2_comment_amd import ORBextractor, ORBmatcher
+        from orb_slam2_comment_amd import matcher as M
+        from orb_slam2_comment_amd.capi import POINT_OBSERVED, POINT_PRESENT
+        from orb_slam2_comment_amd.synth import synth_frame
+        pairs_local = B // 2
+        # local frames: pair k = (scene s, scene s translated by 3 px): 8 scenes -> 16 distinct images per rank
+        uniq = {}
+        for li in range(min(B, 16)):
+            key = (1 + (li // 2) % 8, li % 2)
+            uniq[key] = synth_frame(key[0], W, H, shift_xy=(3 * key[1], 0))
+        self.frames = frames = np.stack([uniq[(1 + (li // 2) % 8, li % 2)] for li in range(B)])
+        self.d_img = d_img = torch.from_numpy(frames).to(dev)
+
+        self.Hn = Hn = max(1, min(args.handles, pairs_local))
+        self.psplit = psplit = [pairs_local // Hn + (1 if h < pairs_local % Hn else 0) for h in range(Hn)]   # pairs per pipeline
+        self.splits = splits = [2 * p for p in psplit]
+        self.offs = offs = [sum(splits[:h]) for h in range(Hn)]
+        self.exts, self.mts, self.streams = [], [], []
+        for h in range(Hn):
+            e = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
+            e.set_lazy_level0(True)          # a monocular Tracking thread never reads mvImagePyramid[0] (src/Frame.cc:174-228)
+            mt = ORBmatcher(0.9, True, device=local_rank)
+            st = torch.cuda.Stream(dev)              # one real (non-null) stream per pipeline: a null handle would mean
+            e.set_stream(st.cuda_stream)             # "the handle's own stream", and extractor and matcher must share one
+            mt.set_stream(st.cuda_stream)
+            self.exts.append(e); self.mts.append(mt); self.streams.append(st)
+        exts, mts, streams = self.exts, self.mts, self.streams
+        self.cap = cap = exts[0].capacity(H, W)
+        sf = exts[0].GetScaleFactors()
+        cam = M.make_camera(KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, (0.0, 0.0, float(W), float(H)), sf, mbf=KITTI_BF,
+                            mb=KITTI_BF / KITTI_FX)
+        # one flat allocation per output set: {KeyPoint[B][cap] | desc[B][cap][32] | count[B] | assign[B/2][cap] |
+        # nmatches[B/2]} are views of it, so the multi-GPU exchange is ONE gather of one contiguous buffer per step
+        nb_k, nb_d, nb_a = B * cap * 28, B * cap * 32, pairs_local * cap * 4
+        off_d = (nb_k + 255) & ~255                      # every view starts 256-byte aligned
+        off_n = (off_d + nb_d + 255) & ~255
+        off_a = (off_n + B * 4 + 255) & ~255
+        off_m = (off_a + nb_a + 255) & ~255
+        self.flat_bytes = flat_bytes = off_m + pairs_local * 4
+
+        def out_set():
+            flat = torch.zeros(flat_bytes, dtype=torch.uint8, device=dev)
+            return {"k": flat[:nb_k].view(torch.int32).view(B, cap, 7), "d": flat[off_d:off_d + nb_d].view(B, cap, 32),
+                    "n": flat[off_n:off_n + B * 4].view(torch.int32), "a": flat[off_a:off_a + nb_a].view(torch.int32).view(pairs_local, cap),
+                    "m": flat[off_m:off_m + pairs_local * 4].view(torch.int32), "st": torch.zeros(B, dtype=torch.int32, device=dev),
+                    "flat": flat}
+
+        # the synthetic map: every last-frame keypoint carries a map point at depth DEPTH in the last camera's frame
+        # (Tlw = I); the current camera is translated so that such a point moves by 3 px -- the shift between the two
+        # rendered views.  World positions are rebuilt from the keypoints of each extraction ON THE DEVICE by a tiny
+        # torch expression (input synthesis for the benchmark, the stand-in for the map that Tracking would hold).
+        Tlw = torch.eye(4, dtype=torch.float32)[:3, :].reshape(1, 12).repeat(pairs_local, 1).contiguous().to(dev)
+        Tc = torch.eye(4, dtype=torch.float32)
+        Tc[0, 3] = float(np.float32(3.0) * np.float32(DEPTH) / np.float32(KITTI_FX))
+        Tcw = Tc[:3, :].reshape(1, 12).repeat(pairs_local, 1).contiguous().to(dev)
+        d_world = torch.zeros((B, cap, 3), dtype=torch.float32, device=dev)
+        d_flags = torch.full((B, cap), POINT_PRESENT | POINT_OBSERVED, dtype=torch.uint8, device=dev)
+
+        def build_map(o):
+            kf = o["k"][0::2].view(torch.float32)                       # last frames of the pairs
+            z = float(DEPTH)
+            d_world[0::2, :, 0] = (kf[..., 0] - KITTI_CX) * (z / KITTI_FX)
+            d_world[0::2, :, 1] = (kf[..., 1] - KITTI_CY) * (z / KITTI_FY)
+            d_world[0::2, :, 2] = z
+
+        self.obuf = obuf = [out_set()]
+        nbuf = args.out_buffers if multi and not rehearsal else 1
+        for _ in range(nbuf - 1):
+            obuf.append(out_set())
+        gstream = torch.cuda.Stream(dev) if nbuf >= 2 else None
+        gdone = [None] * nbuf
+        gout = None
+        if nbuf >= 2 and ctx["rank"] == 0:
+            gout = [torch.zeros((world, flat_bytes), dtype=torch.uint8, device=dev)]   # rank-major, same carve-up per rank
+        stepno = [0]
+        # torch events around the matching of pipeline 0 (recorded on the stream its launches go to): a ring of 256 pairs
+        self.match_ev = match_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(256)] for _ in range(2)]
+        self.record_match = record_match = [False]
+        self.match_calls = match_calls = [0]
+        gather_into, gather_to_rank0 = ctx["gather_into"], ctx["gather_to_rank0"]
+
+        def extract_all(o, which=None):
+            for h, e in enumerate(exts):
+                if which is not None and h != which:
+                    continue
+                sl = slice(offs[h], offs[h] + splits[h])
+                e.extract_batch_device(d_img[sl].data_ptr(), splits[h], H, W, o["k"][sl].data_ptr(), o["d"][sl].data_ptr(),
+                                       cap, o["n"][sl].data_ptr(), o["st"][sl].data_ptr())
+
+        def match_all(o):
+            for h, mt in enumerate(mts):
+                f0, p0 = offs[h], offs[h] // 2
+                if record_match[0] and h == 0:
+                    match_ev[0][match_calls[0] % 256].record(streams[0])
+                # pair j of this pipeline: LastFrame = frame f0 + 2j, CurrentFrame = f0 + 2j + 1 of the shared arrays
+                mt.TrackLastFrameDevice(psplit[h], cam, Tcw[p0:].data_ptr(), Tlw[p0:].data_ptr(), o["k"].data_ptr(),
+                                        o["d"].data_ptr(), o["n"].data_ptr(), cap, f0 + 1, 2, f0, 2, d_world.data_ptr(),
+                                        d_flags.data_ptr(), TRACK_TH, True, o["a"][p0:].data_ptr(), o["m"][p0:].data_ptr())
+                if record_match[0] and h == 0:
+                    match_ev[1][match_calls[0] % 256].record(streams[0])
+                    match_calls[0] += 1
+
+        def step():
+            k = stepno[0] % nbuf
+            stepno[0] += 1
+            o = obuf[k]
+            if gdone[k] is not None:                 # the gather that last read this buffer must be finished
+                for st in streams:
+                    st.wait_event(gdone[k])
+            extract_all(o)
+            match_all(o)
+            if multi:
+                if rehearsal:
+                    torch.cuda.synchronize(dev)
+                    return gather_to_rank0(o["k"].cpu(), o["d"].cpu(), o["n"].cpu())
+                for st in streams:
+                    gstream.wait_stream(st)
+                with torch.cuda.stream(gstream):
+                    out = gather_into(gout, (o["flat"],))
+                    gdone[k] = gstream.record_event()
+                return out
+            return None
+
+        self.extract_all, self.step = extract_all, step
+        # the map of every output set is built once from a first extraction (keypoints are deterministic per image)
+        for o in obuf:
+            extract_all(o)
+            torch.cuda.synchronize(dev)
+            build_map(o)
+        torch.cuda.synchronize(dev)
+
+    def barrier(self):
+        torch, dev = self.ctx["torch"], self.ctx["dev"]
+        torch.cuda.synchronize(dev)              # drains the pipeline streams and the gather stream
+        if self.ctx["multi"]:
+            self.ctx["dist"].barrier()
+        torch.cuda.synchronize(dev)
+
+    def allreduce_max(self, v):
+        if not self.ctx["multi"]:
+            return v
+        torch = self.ctx["torch"]
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if self.ctx["rehearsal"] else self.ctx["dev"])
+        self.ctx["dist"].all_reduce(t, op=self.ctx["dist"].ReduceOp.MAX)
+        return float(t.item())
+
+    def measure(self, stages=True):
+        args, torch, dev, world = self.ctx["args"], self.ctx["torch"], self.ctx["dev"], self.ctx["world"]
+        exts, step, barrier, allreduce_max = self.exts, self.step, self.barrier, self.allreduce_max
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        # ---- the measurement the contract asks for: EXACTLY K steps between barriers -> ms_per_step, value ----------
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt_k = allreduce_max(time.perf_counter() - t0)
+        # ---- the same steps again, R x K of them (>= 1 s), with the per-stage HIP events on: stage_us / roofline -----
+        if stages:
+            for e in exts:
+                e.set_profiling(True)                   # HIP events around every stage, on the launch stream
+            self.record_match[0] = True
+        reps = max(1, int(np.ceil(args.min_time / max(dt_k, 1e-6))))
+        reps = int(allreduce_max(float(reps)))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps * args.steps):
+            step()
+        barrier()
+        dt_long = allreduce_max(time.perf_counter() - t0)
+        steps_long = reps * args.steps
+        res = {"dt_k": dt_k, "dt_long": dt_long, "reps": reps, "steps_long": steps_long,
+               "fps": self.B * world * steps_long / dt_long}                      # the >= 1 s region; `value`
+        o = self.obuf[0]
+        n_host, nm_host = o["n"].cpu().numpy(), o["m"].cpu().numpy()
+        assert int(o["st"].abs().sum().item()) == 0 and n_host.min() > 0, "extraction failed"
+        assert nm_host.min() > 100, "SearchByProjection found too few matches: the synthetic pairs are broken"
+        res["mean_kp"], res["mean_matches"] = round(float(n_host.mean()), 1), round(float(nm_host.mean()), 1)
+        if not stages:
+            return res
+        self.record_match[0] = False
+        st_all = [e.stage_times_us() for e in exts]
+        stage = {k: sum(st[k] for st in st_all) / len(st_all) for k in st_all[0]}
+        for e in exts:
+            e.set_profiling(False)
+        nev = min(self.match_calls[0], 256)
+        stage["match"] = float(np.mean([self.match_ev[0][i].elapsed_time(self.match_ev[1][i]) for i in range(nev)])) * 1e3 if nev else 0.0
+        # pipeline 0 once more, ALONE on the GPU (the other pipelines idle): the stand-alone launch times of its kernels, which
+        # is what rocprofv3 shows for a single-pipeline run; reported beside the contended times of the timed region above
+        torch.cuda.synchronize(dev)
+        exts[0].set_profiling(True)
+        for _ in range(40):
+            self.extract_all(self.obuf[0], which=0)
+        torch.cuda.synchronize(dev)
+        res["stage_alone"] = exts[0].stage_times_us()
+        exts[0].set_profiling(False)
+        res["stage"] = stage
+        res["frames_per_launch"] = sum(self.splits) / len(self.splits)
+        return res
+
+    def close(self):
+        self.ctx["torch"].cuda.synchronize(self.ctx["dev"])
+        for e in self.exts:
+            e.close()
+        self.exts, self.mts, self.obuf, self.d_img = [], [], [], None
+        self.ctx["torch"].cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def secondary_legs(args, torch, dev, local_rank, head):
     """Named secondary measurements (single GPU).  Each leg: warm-up, then a timed region of >= MIN_TIMED_S."""
     from orb_slam2_comment_amd import ORBextractor, ORBmatcher, ORBVocabulary
+    from orb_slam2_comment_amd import matcher as M
+    from orb_slam2_comment_amd.capi import POINT_OBSERVED, POINT_PRESENT
     from orb_slam2_comment_amd.synth import synth_frame, synth_stereo, synth_vocabulary
-    B = d_img.shape[0]
+    exts, o, d_img, cap, extract_all = head.exts, head.obuf[0], head.d_img, head.cap, head.extract_all
+    B = min(d_img.shape[0], 128)              # frames per step of the secondary legs
     out = {}
 
     def sync():
@@ -575,48 +654,105 @@ def secondary_legs(args, torch, dev, local_rank, exts, streams, o, d_img, cap, s
     st = {k: round(sum(s[k] for s in stages) / len(stages), 2) for k in stages[0]}
     for e in exts:
         e.set_profiling(False)
-    out["extract_only"] = {"value": round(B * reps * args.steps / dt, 1), "unit": "frames/s",
+    out["extract_only"] = {"value": round(head.B * reps * args.steps / dt, 1), "unit": "frames/s",
                            "what": "configs[1]: ORBextractor::operator() over %d resident 1241x376 frames per step "
-                                   "(%d pipelines), nothing else" % (B, len(exts)),
+                                   "(%d pipelines, monocular handles: mvImagePyramid[0] on demand), nothing else" % (head.B, len(exts)),
                            "ms_per_step": round(dt / (reps * args.steps) * 1e3, 4), "timed_s": round(dt, 3), "stage_us": st}
 
     cur = torch.cuda.Stream(dev)               # every handle of the legs below launches on this one stream
     mt = ORBmatcher(0.9, True, device=local_rank)
     mt.set_stream(cur.cuda_stream)
-    # ---- configs[2]: stereo front-end: extract left+right + Frame::ComputeStereoMatches --------------------------
-    st_frames = []
-    for p in range(8):
-        l, r = synth_stereo(1 + p, W, H)
-        st_frames += [l, r]
-    st_frames = np.stack([st_frames[i % 16] for i in range(B)])
-    d_simg = torch.from_numpy(st_frames).to(dev)
-    sext = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
-    sext.set_stream(cur.cuda_stream)
-    s_ur = torch.zeros((B // 2, cap), dtype=torch.float32, device=dev)
-    s_dp = torch.zeros((B // 2, cap), dtype=torch.float32, device=dev)
-    s_nm = torch.zeros(B // 2, dtype=torch.int32, device=dev)
+    # ---- configs[2] as ONE leg: the stereo Tracking step.  Per step Bs stereo frames: the two extractors of a stereo
+    # sensor on two streams (src/Frame.cc:78-81 runs them on two threads), Frame::ComputeStereoMatches for every frame,
+    # then SearchByProjection(CurrentFrame, LastFrame, th = 7, bMono = false) with the `ur` gate for every (t, t+1) pair
+    # (src/Tracking.cc:880-885, src/ORBmatcher.cc:1407-1413).  The map: every last-frame keypoint with a stereo depth
+    # carries a map point at that depth; the current camera is the last one rotated about y by 3 px / fx, so that
+    # projections land on the scene's 3-px shift whatever the depth and the projected `ur` keeps the measured disparity.
+    Bs = B // 2
+    lefts, rights = [], []
+    for p in range(4):
+        for sh in (0, 3):
+            l, r = synth_stereo(1 + p, W, H, shift_xy=(sh, 0))
+            lefts.append(l); rights.append(r)
+    d_left = torch.from_numpy(np.stack([lefts[i % 8] for i in range(Bs)])).to(dev)
+    d_right = torch.from_numpy(np.stack([rights[i % 8] for i in range(Bs)])).to(dev)
+    sL, sR = cur, torch.cuda.Stream(dev)
+    eL = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
+    eR = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
+    eL.set_stream(sL.cuda_stream); eR.set_stream(sR.cuda_stream)
+    so = {}
+    for side in "LR":
+        so["k" + side] = torch.zeros((Bs, cap, 7), dtype=torch.int32, device=dev)
+        so["d" + side] = torch.zeros((Bs, cap, 32), dtype=torch.uint8, device=dev)
+        so["n" + side] = torch.zeros(Bs, dtype=torch.int32, device=dev)
+        so["s" + side] = torch.zeros(Bs, dtype=torch.int32, device=dev)
+    s_ur = torch.full((Bs, cap), -1.0, dtype=torch.float32, device=dev)
+    s_dp = torch.full((Bs, cap), -1.0, dtype=torch.float32, device=dev)
+    s_nm = torch.zeros(Bs, dtype=torch.int32, device=dev)
+    t_a = torch.zeros((Bs // 2, cap), dtype=torch.int32, device=dev)
+    t_m = torch.zeros(Bs // 2, dtype=torch.int32, device=dev)
     mbf = KITTI_BF
     mb = mbf / KITTI_FX                        # Examples/Stereo/KITTI00-02.yaml:8,25
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    scam = M.make_camera(KITTI_FX, KITTI_FY, KITTI_CX, KITTI_CY, (0.0, 0.0, float(W), float(H)), eL.GetScaleFactors(),
+                         mbf=mbf, mb=mb)
+    th_y = 3.0 / KITTI_FX
+    Tc = torch.eye(4, dtype=torch.float32)
+    Tc[0, 0] = Tc[2, 2] = float(np.cos(th_y)); Tc[0, 2] = float(np.sin(th_y)); Tc[2, 0] = -float(np.sin(th_y))
+    sTcw = Tc[:3, :].reshape(1, 12).repeat(Bs // 2, 1).contiguous().to(dev)
+    sTlw = torch.eye(4, dtype=torch.float32)[:3, :].reshape(1, 12).repeat(Bs // 2, 1).contiguous().to(dev)
+    s_world = torch.zeros((Bs, cap, 3), dtype=torch.float32, device=dev)
+    s_flags = torch.zeros((Bs, cap), dtype=torch.uint8, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def stereo_extract_and_match():
+        eL.extract_batch_device(d_left.data_ptr(), Bs, H, W, so["kL"].data_ptr(), so["dL"].data_ptr(), cap, so["nL"].data_ptr(),
+                                so["sL"].data_ptr())
+        sR.wait_stream(sL)                     # the right extraction of step k+1 must not overtake the stereo search of step k
+        eR.extract_batch_device(d_right.data_ptr(), Bs, H, W, so["kR"].data_ptr(), so["dR"].data_ptr(), cap, so["nR"].data_ptr(),
+                                so["sR"].data_ptr())
+        sL.wait_stream(sR)
+        ev[1].record(sL)
+        mt.ComputeStereoMatchesDevice(eL, 0, 1, eR, 0, 1, Bs, so["kL"].data_ptr(), so["dL"].data_ptr(), so["nL"].data_ptr(),
+                                      so["kR"].data_ptr(), so["dR"].data_ptr(), so["nR"].data_ptr(), cap, mbf, mb,
+                                      s_ur.data_ptr(), s_dp.data_ptr(), s_nm.data_ptr())
+        ev[2].record(sL)
 
     def stereo_step():
-        ev[0].record(cur)
-        sext.extract_batch_device(d_simg.data_ptr(), B, H, W, o["k"].data_ptr(), o["d"].data_ptr(), cap,
-                                  o["n"].data_ptr(), o["st"].data_ptr())
-        ev[1].record(cur)
-        mt.ComputeStereoMatchesDevice(sext, 0, 2, sext, 1, 2, B // 2, o["k"].data_ptr(), o["d"].data_ptr(),
-                                      o["n"].data_ptr(), o["k"].data_ptr(), o["d"].data_ptr(), o["n"].data_ptr(), cap, mbf, mb,
-                                      s_ur.data_ptr(), s_dp.data_ptr(), s_nm.data_ptr())
-        ev[2].record(cur)
+        ev[0].record(sL)
+        stereo_extract_and_match()
+        # pair j: LastFrame = left frame 2j, CurrentFrame = left frame 2j + 1; mvuRight of the current frame gates `ur`
+        mt.TrackLastFrameDevice(Bs // 2, scam, sTcw.data_ptr(), sTlw.data_ptr(), so["kL"].data_ptr(), so["dL"].data_ptr(),
+                                so["nL"].data_ptr(), cap, 1, 2, 0, 2, s_world.data_ptr(), s_flags.data_ptr(), STEREO_TH, False,
+                                t_a.data_ptr(), t_m.data_ptr(), d_u_right=s_ur.data_ptr())
+        ev[3].record(sL)
+
+    stereo_extract_and_match()                 # the map, once (input synthesis): unproject the last frames' keypoints
+    sync()
+    kf = so["kL"].view(torch.float32)
+    valid = (s_dp > 0) & (torch.arange(cap, device=dev)[None, :] < so["nL"][:, None])
+    z = torch.where(valid, s_dp, torch.ones_like(s_dp))
+    s_world[..., 0] = (kf[..., 0] - KITTI_CX) * z / KITTI_FX
+    s_world[..., 1] = (kf[..., 1] - KITTI_CY) * z / KITTI_FY
+    s_world[..., 2] = z
+    s_flags[:] = torch.where(valid, POINT_PRESENT | POINT_OBSERVED, 0).to(torch.uint8)
     dts, reps = leg(stereo_step, args.steps)
     sync()
-    out["stereo"] = {"value": round(B // 2 * reps * args.steps / dts, 1), "unit": "stereo pairs/s",
-                     "what": "configs[2]: extract left+right (%d interleaved 1241x376 pairs, one pipeline) + device-resident "
-                             "Frame::ComputeStereoMatches, fx 718.856 bf 386.1448" % (B // 2),
+    assert int(so["sL"].abs().sum().item()) == 0 and int(so["sR"].abs().sum().item()) == 0, "stereo extraction failed"
+    tm = float(t_m.float().mean().item())
+    assert tm > 50, "stereo SearchByProjection found too few matches (%.1f): the synthetic stereo sequence is broken" % tm
+    out["stereo"] = {"value": round(Bs * reps * args.steps / dts, 1), "unit": "stereo frames/s",
+                     "what": "configs[2] as one leg: per step %d stereo frames 1241x376: extract left and right (two handles, two "
+                             "streams) + device-resident Frame::ComputeStereoMatches (fx 718.856, bf 386.1448) + device-resident "
+                             "SearchByProjection(CurrentFrame, LastFrame, th=7, bMono=false, `ur` gate on mvuRight) for the %d "
+                             "(t, t+1) pairs; map points at the stereo depth of the last frame" % (Bs, Bs // 2),
                      "ms_per_step": round(dts / (reps * args.steps) * 1e3, 4), "timed_s": round(dts, 3),
-                     "stage_us": {"extract": round(ev[0].elapsed_time(ev[1]) * 1e3, 1),
-                                  "stereo_match": round(ev[1].elapsed_time(ev[2]) * 1e3, 1)},
-                     "mean_stereo_matches_per_pair": round(float(s_nm.float().mean().item()), 1)}
+                     "stage_us": {"extract_left_and_right": round(ev[0].elapsed_time(ev[1]) * 1e3, 1),
+                                  "stereo_match": round(ev[1].elapsed_time(ev[2]) * 1e3, 1),
+                                  "search_by_projection": round(ev[2].elapsed_time(ev[3]) * 1e3, 1)},
+                     "mean_stereo_matches_per_frame": round(float(s_nm.float().mean().item()), 1),
+                     "mean_projection_matches_per_pair": round(tm, 1)}
+    eR.set_stream(0)
+    sext, d_simg, Bb = eL, d_img, B            # the BoW leg below extracts the monocular frames with this handle (stream `cur`)
 
     # ---- configs[4]: EuRoC 752x480 @2000 + SearchForInitialization(windowSize 100, nnratio 0.9) ------------------
     EW, EH, ENF = 752, 480, 2000
@@ -674,9 +810,9 @@ def secondary_legs(args, torch, dev, local_rank, exts, streams, o, d_img, cap, s
     b_nm = torch.zeros(B // 2, dtype=torch.int32, device=dev)
 
     def bow_step():
-        sext.extract_batch_device(d_simg.data_ptr(), B, H, W, o["k"].data_ptr(), o["d"].data_ptr(), cap,
+        sext.extract_batch_device(d_simg.data_ptr(), Bb, H, W, o["k"].data_ptr(), o["d"].data_ptr(), cap,
                                   o["n"].data_ptr(), o["st"].data_ptr())
-        voc.transform_device(B, o["d"].data_ptr(), o["n"].data_ptr(), cap, 4, b_word.data_ptr(), b_w.data_ptr(),
+        voc.transform_device(Bb, o["d"].data_ptr(), o["n"].data_ptr(), cap, 4, b_word.data_ptr(), b_w.data_ptr(),
                              b_node.data_ptr(), b_ids.data_ptr(), b_vals.data_ptr(), b_n.data_ptr())
         side = (o["k"].data_ptr(), o["d"].data_ptr(), o["n"].data_ptr(), b_node.data_ptr())
         bm.SearchByBoWDevice(B // 2, cap, side, 0, 2, side, 1, 2, b_m12.data_ptr(), b_nm.data_ptr(), 50)
@@ -693,7 +829,7 @@ def secondary_legs(args, torch, dev, local_rank, exts, streams, o, d_img, cap, s
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def dry_run(args, dist, torch, world, rank, multi, my_pairs, gather_to_rank0):
+def dry_run(args, dist, torch, world, rank, multi, my_pairs, gather_to_rank0, B):
     """GPU-less rehearsal of the multi-rank control flow: pair sharding + gather of fabricated result slots."""
     cap = 64
 
@@ -726,9 +862,11 @@ def dry_run(args, dist, torch, world, rank, multi, my_pairs, gather_to_rank0):
     if rank == 0:
         emit_json({"metric": "dry run: control flow only, no extraction", "value": None, "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                          "higher_is_better": True, "scaling": "weak" if args.frames_per_gpu is not None else "strong", "vs_baseline": None,
+                          "dtype": "u8", "data": "synthetic",
                           "config": {"workload": "dry run (gloo, no GPU): pair sharding + gather of fabricated slots",
-                                     "pairs_per_rank": len(my_pairs), "parallelism": "pair-sharded x%d" % world},
+                                     "pairs_per_rank": len(my_pairs), "frames_per_gpu_per_step": B, "global_batch": B * world,
+                                     "parallelism": "pair-sharded x%d" % world},
                           "gather_verified": bool(ok)})
     if multi:
         dist.destroy_process_group()

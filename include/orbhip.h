@@ -88,6 +88,16 @@ int orbhip_extractor_capacity(orbhip_extractor *e, int rows, int cols, int *cap)
  * GaussianBlur(7x7, sigma 2) on 8U; out = sat((sum_v sum_u w_v w_u p + 2^15) >> 16)). */
 int orbhip_extractor_set_blur_kernel(orbhip_extractor *e, const int32_t w[7]);
 
+/* mvImagePyramid[0] on demand (include/ORBextractor.h:85; only Frame::ComputeStereoMatches, src/Frame.cc:563-580, ever
+ * reads it -- a monocular Tracking thread never does).  on != 0: extractions stop writing the padded level-0 plane
+ * (copyMakeBorder of the image, src/ORBextractor.cc:1127); FAST and the descriptor kernel read level 0 from the caller's
+ * image (BORDER_REFLECT_101 by index where a border keypoint's window overshoots it), results are bit-identical.  The
+ * first accessor that needs the plane afterwards (orbhip_pyramid_level / _download / orbhip_blurred_level_download for
+ * level 0, orbhip_compute_stereo_matches*) writes it then, from the image buffer of the last extraction: callers of
+ * orbhip_extract_batch_device must leave that buffer untouched until then (host entry points keep their own copy).
+ * Default 0: every extraction materialises it, as the reference does. */
+int orbhip_extractor_set_lazy_level0(orbhip_extractor *e, int on);
+
 /* ORBextractor::operator()(image, mask(ignored), keypoints, descriptors)
  * (src/ORBextractor.cc:1043-1105).  image: rows x cols uint8, row stride `stride` bytes (host).
  * kps[cap], desc[cap*32] host buffers; *n = number of keypoints (0 is success). */
@@ -132,8 +142,8 @@ int orbhip_level_candidates(orbhip_extractor *e, int frame, int level, int32_t *
 
 /* Per-stage device time, microseconds, averaged over the extract calls made since
  * orbhip_extractor_set_profiling(e, 1) (at most the last 256), measured with HIP events on the
- * handle's stream: [0] pyramid (7 launches), [1] FAST+NMS cells, [2] octree, [3] blur (no launch of its own any
- * more: the descriptor kernel blurs the patches it samples, so this is the gap between two events), [4] blur of the
+ * handle's stream: [0] pyramid (7 launches), [1] FAST+NMS cells, [2] octree, [3] always 0 (the separate blur stage of
+ * round 1: the descriptor kernel blurs the patches it samples, nothing is launched or timed there), [4] blur of the
  * patches + orientation + descriptors, [5] whole call. */
 int orbhip_extractor_set_profiling(orbhip_extractor *e, int on);
 int orbhip_extractor_stage_times(orbhip_extractor *e, float us[6]);

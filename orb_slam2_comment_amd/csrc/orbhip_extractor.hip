@@ -384,7 +384,8 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ im
 {
     int bx, fr;
     xcd_remap(bx, fr);
-    if (bx == 0 && threadIdx.x == 0) status[fr] = 0;   // the frame's status word starts every extraction at ORBHIP_OK
+    if (status && bx == 0 && threadIdx.x == 0) status[fr] = 0;   // the frame's status word starts every extraction at ORBHIP_OK
+                                                                 // (null: the lazy level-0 copy after an extraction)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint8_t *src = images + (size_t)fr * frame_stride;
     uint8_t *frame = pyr + (size_t)fr * frame_bytes;
@@ -498,7 +499,7 @@ __device__ __forceinline__ unsigned long long stamp_now()
 template <int SW, bool STAMPS = false>
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, const FastCell *__restrict__ cells,
                                                     int *__restrict__ cell_cnt, uint32_t *__restrict__ cell_kp,
-                                                    FastParams P)
+                                                    FastParams P, const uint8_t *__restrict__ images, size_t frame_stride)
 {
     extern __shared__ uint32_t lds[];
     constexpr int SB = SW * 4;                 // bytes per staged row
@@ -545,7 +546,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     // groups past the sub-image re-read its last rows (scalar clamp) into LDS rows that nothing looks at.
     {
         const int c = lane & (LPR - 1), r = lane / LPR;
-        const uint8_t *sb = pyr + (size_t)fr * P.frame_bytes + cd.src_off;
+        // level-0 cells of a handle that does not materialise mvImagePyramid[0] read the caller's image itself (a FAST
+        // sub-image never reaches the REFLECT_101 frame: the cell grid starts 13 px inside the level)
+        const uint8_t *sb = cd.img ? images + (size_t)fr * frame_stride + cd.src_off : pyr + (size_t)fr * P.frame_bytes + cd.src_off;
         const uint32_t voff = (uint32_t)(__mul24(r, pitch) + 4 * c);
         uint32_t *sdst = simg + (r * SW + c);
         if (c < SW) {
@@ -1262,7 +1265,10 @@ constexpr int kWinLoads = 9;                  // 9 x 5 = 45 >= 43 rows
 constexpr int kWinWords = kWinRows * kWinDw + 7;   // + the dwords the last column group reads past the last row
 constexpr int kHPairs = 22, kHGroups = 10;    // row-pass results: 22 pair-rows x 10 groups of 4 columns (uint4 each)
 
-__global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restrict__ pyr, PyrGeom G,
+#ifndef ORBHIP_DESC_WAVES
+#define ORBHIP_DESC_WAVES 6   // resident waves per SIMD the register allocation is held to (78 VGPRs; 4: 232 k, 5: 240-244 k, 6: 235-246 k frames/s in tools/ab_build.sh)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBHIP_DESC_WAVES, ORBHIP_DESC_WAVES))) void k_describe_fused(const uint8_t *__restrict__ pyr, PyrGeom G,
                                                         const uint32_t *__restrict__ sel_kp,
                                                         const int *__restrict__ sel_cnt,
                                                         const DiscTab *__restrict__ disc,
@@ -1271,7 +1277,8 @@ __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restric
                                                         orbhip_keypoint *__restrict__ out_kp,
                                                         uint8_t *__restrict__ out_desc, int cap,
                                                         int *__restrict__ out_n, int *__restrict__ status, int per_wave, BlurW W,
-                                                        const uint32_t *__restrict__ hitem_tab)
+                                                        const uint32_t *__restrict__ hitem_tab,
+                                                        const uint8_t *__restrict__ images, int img_stride, size_t img_frame_stride)
 {
     __shared__ uint32_t swin[4][kWinWords];
     __shared__ uint4 shsum[4][kHPairs * kHGroups];
@@ -1329,16 +1336,35 @@ __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restric
     const uint32_t kv = sel_kp[(size_t)b * G.kp_cap_total + slot];
     const int kx = (int)(kv & 0xfff) + 16, ky = (int)((kv >> 12) & 0xfff) + 16;  // + minBorder (:843-844)
     const int resp = (int)(kv >> 24);
-    const size_t fo = (size_t)b * G.frame_bytes + G.lv[level].plane_off + (size_t)kEdge * pitch + kPadL;
-    const uint8_t *wb = pyr + fo + (size_t)(ky - 21) * pitch + (kx - 21);   // window byte (0, 0), uniform
     uint32_t wvv[kWinLoads];
-    {
-        const uint32_t voff = (uint32_t)(__mul24(srow, pitch) + 4 * scol);
+    // level 0 of a handle that does not materialise mvImagePyramid[0]: the window comes from the caller's image; the up
+    // to 5 px it overshoots the image near the border are REFLECT_101 by index (what copyMakeBorder would have written)
+    const bool from_img = images != nullptr && level == 0;
+    const bool inside = kx >= 21 && kx + 22 < G.lv[0].w && ky >= 21 && ky + 21 < G.lv[0].h;
+    if (from_img && !inside) {   // wave-uniform: a border keypoint gathers its window byte by byte
+        const uint8_t *ib = images + (size_t)b * img_frame_stride;
+        uint32_t cx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cx[k] = (uint32_t)reflect101(kx - 21 + 4 * scol + k, G.lv[0].w);
+#pragma unroll
+        for (int u = 0; u < kWinLoads; ++u) {
+            wvv[u] = 0u;
+            if (lane < kWinRpi * kWinDw && (u < kWinLoads - 1 || srow < kWinRows - (kWinLoads - 1) * kWinRpi)) {
+                const uint8_t *rp = ib + (size_t)((uint32_t)reflect101(ky - 21 + srow + u * kWinRpi, G.lv[0].h) * (uint32_t)img_stride);
+                wvv[u] = (uint32_t)rp[cx[0]] | ((uint32_t)rp[cx[1]] << 8) | ((uint32_t)rp[cx[2]] << 16) | ((uint32_t)rp[cx[3]] << 24);
+            }
+        }
+    } else {
+        const int wpitch = from_img ? img_stride : pitch;
+        const uint8_t *wb = from_img
+            ? images + (size_t)b * img_frame_stride + (size_t)(ky - 21) * img_stride + (kx - 21)
+            : pyr + (size_t)b * G.frame_bytes + G.lv[level].plane_off + (size_t)kEdge * pitch + kPadL + (size_t)(ky - 21) * pitch + (kx - 21);   // window byte (0, 0), uniform
+        const uint32_t voff = (uint32_t)(__mul24(srow, wpitch) + 4 * scol);
 #pragma unroll
         for (int u = 0; u < kWinLoads; ++u) {
             wvv[u] = 0u;
             if (lane < kWinRpi * kWinDw && (u < kWinLoads - 1 || srow < kWinRows - (kWinLoads - 1) * kWinRpi))
-                __builtin_memcpy(&wvv[u], wb + (uint32_t)(u * kWinRpi * pitch) + voff, 4);
+                __builtin_memcpy(&wvv[u], wb + (uint32_t)(u * kWinRpi * wpitch) + voff, 4);
         }
     }
     __builtin_amdgcn_wave_barrier();                     // the previous keypoint's LDS reads are done
@@ -1621,6 +1647,33 @@ static int build_pyr_tables(orbhip_extractor *e)
     return ORBHIP_OK;
 }
 
+// One cell of the FAST kernel's table.  img_stride > 0: a level-0 cell that reads the caller's image (row stride
+// img_stride) instead of the padded level-0 plane.
+static FastCell make_fast_cell(const PyrGeom &G, const CellDesc &c, int img_stride)
+{
+    const LevelGeom &Lc = G.lv[c.level];
+    FastCell f; memset(&f, 0, sizeof(f));
+    // The sub-image is staged so that its first detection column (x0 + 3) lands on a dword boundary of the LDS row
+    // whatever x0 is: LDS column 0 = x0 - 5 (global rows are read with byte-unaligned dword loads), i.e. the
+    // kernel's "a" is the constant 1 and the first centre column is LDS column 8.  A row of 31 or 32 detection
+    // columns is then 8 four-pixel groups, never 9 -- for 32 rows that is 256 dense items = exactly 4 rounds of
+    // the wavefront instead of 4.5 (5).
+    const int a = kFastLead, gxb = c.x0 - a, sw = c.x1 - c.x0, shh = c.y1 - c.y0;
+    if (img_stride > 0 && c.level == 0) {
+        f.src_off = (unsigned)(c.y0 * img_stride + gxb - 4);   // x0 >= 13: never left of the image
+        f.pitch = (unsigned short)img_stride; f.img = 1;
+    } else {
+        f.src_off = Lc.plane_off + (unsigned)((kEdge + c.y0) * Lc.pitch + kPadL + gxb - 4);
+        f.pitch = (unsigned short)Lc.pitch;
+    }
+    f.sw = (unsigned char)sw; f.sh = (unsigned char)shh; f.a = (unsigned char)a;
+    f.kpx = (short)(c.offx - 4 - a); f.kpy = (short)(c.offy + 3);
+    const int dwc = sw - 6, c_lo = a + 7, c_hi = c_lo + dwc;
+    const int ngrp = dwc > 0 ? ((c_hi - 1) >> 2) - (c_lo >> 2) + 1 : 1;
+    f.magic = ((1u << 20) + ngrp - 1) / ngrp;
+    return f;
+}
+
 // Bind the handle to an image size: level geometry (:1111-1113), cell table (:769-829),
 // OpenCV resize tables, blur tiles.
 static int bind_geometry(orbhip_extractor *e, int rows, int cols)
@@ -1722,23 +1775,8 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         }
         e->fast_lds_bytes = (F2.img_words + F2.score_words + F2.list_words) * 4;
         e->cells2.clear();
-        for (const CellDesc &c : e->cells) {
-            const LevelGeom &Lc = G.lv[c.level];
-            FastCell f; memset(&f, 0, sizeof(f));
-            // The sub-image is staged so that its first detection column (x0 + 3) lands on a dword boundary of the LDS row
-            // whatever x0 is: LDS column 0 = x0 - 5 (global rows are read with byte-unaligned dword loads), i.e. the
-            // kernel's "a" is the constant 1 and the first centre column is LDS column 8.  A row of 31 or 32 detection
-            // columns is then 8 four-pixel groups, never 9 -- for 32 rows that is 256 dense items = exactly 4 rounds of
-            // the wavefront instead of 4.5 (5).
-            const int a = kFastLead, gxb = c.x0 - a, sw = c.x1 - c.x0, shh = c.y1 - c.y0;
-            f.src_off = Lc.plane_off + (unsigned)((kEdge + c.y0) * Lc.pitch + kPadL + gxb - 4);
-            f.pitch = (unsigned short)Lc.pitch; f.sw = (unsigned char)sw; f.sh = (unsigned char)shh; f.a = (unsigned char)a;
-            f.kpx = (short)(c.offx - 4 - a); f.kpy = (short)(c.offy + 3);
-            const int dwc = sw - 6, c_lo = a + 7, c_hi = c_lo + dwc;
-            const int ngrp = dwc > 0 ? ((c_hi - 1) >> 2) - (c_lo >> 2) + 1 : 1;
-            f.magic = ((1u << 20) + ngrp - 1) / ngrp;
-            e->cells2.push_back(f);
-        }
+        for (const CellDesc &c : e->cells) e->cells2.push_back(make_fast_cell(G, c, 0));
+        e->cells_stride = 0;
         FastParams &FP = e->fast_params;
         memset(&FP, 0, sizeof(FP));
         FP.img_words = F2.img_words; FP.score_words = F2.score_words;
@@ -1807,9 +1845,53 @@ static int ensure_batch(orbhip_extractor *e, int batch)
 // Every extraction entry calls this before it enqueues anything: whatever the accessors cached about the previous
 // batch (the lazily produced blurred planes) is stale from here on -- also when the work itself is a graph replay that
 // never passes through launch_pipeline.
-static void begin_extraction(orbhip_extractor *e)
+static int begin_extraction(orbhip_extractor *e, const uint8_t *d_images, int stride, size_t frame_stride)
 {
     e->blur_valid = false;
+    // mvImagePyramid[0] on demand (orbhip_extractor_set_lazy_level0): FAST and the descriptor kernel read level 0 from
+    // the caller's image, the padded plane is only written when an accessor asks for it (ensure_level0).  Needs level 1
+    // to be resized from the image too (its table-driven kernel does; the general kernel reads the padded plane).
+    const bool lazy = e->lazy_l0 && e->G.nlevels > 1 && e->ptab_rows[1] && stride <= 65535 &&
+                      (unsigned long long)e->G.rows * (unsigned long long)stride < (1ull << 31);
+    const int want = lazy ? stride : 0;
+    if (want != e->cells_stride && !e->cells.empty()) {
+        // level-0 entries of the FAST cell table follow the image's row stride: rebuilt when it changes (rare), never
+        // inside a stream capture
+        ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+        drop_graph(e);
+        for (size_t i = 0; i < e->cells.size(); ++i)
+            if (e->cells[i].level == 0) e->cells2[i] = make_fast_cell(e->G, e->cells[i], want);
+        ORBHIP_HIP_CHECK(hipMemcpyAsync(e->d_cells2, e->cells2.data(), e->cells2.size() * sizeof(FastCell), hipMemcpyHostToDevice, e->stream));
+        ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    }
+    e->cells_stride = want;
+    e->l0_in_image = lazy;
+    e->l0_valid = !lazy;
+    e->src_images = d_images; e->src_stride = stride; e->src_frame_stride = frame_stride;
+    return ORBHIP_OK;
+}
+
+// The padded level-0 planes of the last batch, for the accessors that read them (orbhip_pyramid_level*, the blurred
+// planes, ComputeStereoMatches): written now, from the image buffer of the last extraction, if that extraction skipped
+// them.  `consumer`: a stream that will read the planes (ordered behind the copy), or null.
+int orbhip::ensure_level0(orbhip_extractor *e, hipStream_t consumer)
+{
+    if (!e || !e->bound || e->last_batch <= 0) return ORBHIP_OK;
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    if (!e->l0_valid) {
+        PyrLevelTab none; memset(&none, 0, sizeof(none));
+        const int nb0 = (e->ptab[0].units + 3) / 4;
+        hipLaunchKernelGGL(k_pyr_base, dim3(nb0, e->last_batch), dim3(256), 0, e->stream, e->src_images, e->src_stride,
+                           e->src_frame_stride, e->d_pyr, e->G.frame_bytes, e->ptab[0], none, nb0, (int *)nullptr);
+        ORBHIP_HIP_CHECK(hipGetLastError());
+        e->l0_valid = true;
+    }
+    if (consumer && consumer != e->stream) {
+        if (!e->ev_l0) ORBHIP_HIP_CHECK(hipEventCreateWithFlags(&e->ev_l0, hipEventDisableTiming));
+        ORBHIP_HIP_CHECK(hipEventRecord(e->ev_l0, e->stream));
+        ORBHIP_HIP_CHECK(hipStreamWaitEvent(consumer, e->ev_l0, 0));
+    }
+    return ORBHIP_OK;
 }
 
 // `frame0`: first internal frame slot of this launch (the host path runs a batch as several chunks, each in its own
@@ -1832,6 +1914,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     hipEvent_t *ev = prof ? &e->ev[(size_t)(e->prof_calls % orbhip_extractor::kProfRing) * orbhip_extractor::kProfEv] : nullptr;
     int *status = d_status ? d_status : e->d_status + frame0;
     const int sm = ORBHIP_STAGE_MASK(e);
+    const bool lazy = e->l0_in_image;   // begin_extraction: level 0 is read from the image, its padded plane is not written
     if (!(sm & 1))   // k_pyr_base clears the status words itself
         hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
     if (prof) (void)hipEventRecord(ev[0], s);
@@ -1840,7 +1923,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         const bool l1_rows = G.nlevels > 1 && e->ptab_rows[1];
         PyrLevelTab T1 = e->ptab[1];
         if (!l1_rows) memset(&T1, 0, sizeof(T1));
-        const int nb0 = (e->ptab[0].units + 3) / 4, nb1 = (T1.units + 3) / 4;
+        const int nb0 = lazy ? 0 : (e->ptab[0].units + 3) / 4, nb1 = (T1.units + 3) / 4;   // lazy implies l1_rows: nb1 > 0
         hipLaunchKernelGGL(k_pyr_base, dim3(nb0 + nb1, batch), dim3(256), 0, s, d_images, stride, frame_stride, b_pyr,
                            G.frame_bytes, e->ptab[0], T1, nb0, status);
         for (int l = l1_rows ? 2 : 1; l < G.nlevels; ++l) {
@@ -1865,11 +1948,11 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         if ((unsigned long long)G.ncells_total * G.ncells_total * (unsigned long long)batch >= (1ull << 32)) {
             set_error("batch too large for the FAST kernel's work mapping"); return ORBHIP_E_SIZE;
         }
-#define ORBHIP_FAST2(SWv) hipLaunchKernelGGL(k_fast_cells<SWv>, grid, dim3(64), lb, s, b_pyr, e->d_cells2, b_cell_cnt, b_cell_kp, P)
+#define ORBHIP_FAST2(SWv) hipLaunchKernelGGL(k_fast_cells<SWv>, grid, dim3(64), lb, s, b_pyr, e->d_cells2, b_cell_cnt, b_cell_kp, P, d_images, frame_stride)
 #ifdef ORBHIP_DEVTOOLS
         P.dev = e->fast_variant;
         if (e->fast_variant == 2 && e->fast_lds.strideW == 11)   // stamped diagnostic build (tools/fast_ab.py)
-            hipLaunchKernelGGL((k_fast_cells<11, true>), grid, dim3(64), lb, s, b_pyr, e->d_cells2, b_cell_cnt, b_cell_kp, P);
+            hipLaunchKernelGGL((k_fast_cells<11, true>), grid, dim3(64), lb, s, b_pyr, e->d_cells2, b_cell_cnt, b_cell_kp, P, d_images, frame_stride);
         else
 #endif
         switch (e->fast_lds.strideW) {
@@ -1900,7 +1983,8 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         const dim3 grid((G.kp_cap_total + 4 * kDescPerWave - 1) / (4 * kDescPerWave), batch);
         hipLaunchKernelGGL(k_describe_fused, grid, dim3(256), 0, s, b_pyr, G, b_sel, b_sel_cnt, e->d_disc, e->d_disc_off2,
                            e->d_patternf, d_kps, d_desc, cap, d_n, status, kDescPerWave, e->blurw,
-                           reinterpret_cast<const uint32_t *>(e->d_disc_off2 + 768));
+                           reinterpret_cast<const uint32_t *>(e->d_disc_off2 + 768), lazy ? d_images : (const uint8_t *)nullptr, stride,
+                           frame_stride);
     }
     if (prof) { (void)hipEventRecord(ev[4], s); e->prof_calls++; }
     e->last_batch = frame0 + batch;
@@ -2041,6 +2125,7 @@ void orbhip_extractor_destroy(orbhip_extractor *e)
     for (hipEvent_t v : e->ev_chunk) (void)hipEventDestroy(v);
     if (e->s_in) (void)hipStreamDestroy(e->s_in);
     if (e->s_out) (void)hipStreamDestroy(e->s_out);
+    if (e->ev_l0) (void)hipEventDestroy(e->ev_l0);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -2081,6 +2166,16 @@ int orbhip_extractor_set_blur_kernel(orbhip_extractor *e, const int32_t w[7])
     return ORBHIP_OK;
 }
 
+int orbhip_extractor_set_lazy_level0(orbhip_extractor *e, int on)
+{
+    if (!e) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    drop_graph(e);   // which kernels run, and their arguments, depend on it
+    e->lazy_l0 = on != 0;
+    return ORBHIP_OK;
+}
+
 int orbhip_extract_batch_device(orbhip_extractor *e, const void *d_images, int batch, int rows, int cols,
                                 int stride, size_t frame_stride, void *d_kps, void *d_desc, int cap,
                                 void *d_n, void *d_status)
@@ -2094,7 +2189,7 @@ int orbhip_extract_batch_device(orbhip_extractor *e, const void *d_images, int b
     if (rc) return rc;
     rc = ensure_batch(e, batch);
     if (rc) return rc;
-    begin_extraction(e);
+    if ((rc = begin_extraction(e, (const uint8_t *)d_images, stride, frame_stride))) return rc;
     return launch_pipeline(e, (const uint8_t *)d_images, batch, stride, frame_stride, (orbhip_keypoint *)d_kps,
                            (uint8_t *)d_desc, cap, (int *)d_n, (int *)d_status);
 }
@@ -2163,7 +2258,7 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));   // the staging buffer of the previous call is free
     rc = ensure_batch(e, batch);
     if (rc) return rc;
-    begin_extraction(e);
+    if ((rc = begin_extraction(e, e->d_img, dstride, fbytes))) return rc;   // frame f of this call = e->d_img + f * fbytes
     int *h_n = reinterpret_cast<int *>(e->h_out), *h_st = h_n + batch;
     orbhip_keypoint *h_kp = reinterpret_cast<orbhip_keypoint *>(h_st + batch);
     uint8_t *h_desc = reinterpret_cast<uint8_t *>(h_kp + (size_t)batch * cap);
@@ -2316,6 +2411,7 @@ int orbhip_pyramid_level(orbhip_extractor *e, int frame, int level, int *rows, i
 {
     if (!e || !e->bound || frame < 0 || frame >= e->last_batch || level < 0 || level >= e->nlevels) return ORBHIP_E_ARG;
     const LevelGeom &L = e->G.lv[level];
+    if (level == 0 && d_roi) { if (int rc = ensure_level0(e, nullptr)) return rc; }
     if (rows) *rows = L.h;
     if (cols) *cols = L.w;
     if (stride) *stride = L.pitch;
@@ -2358,6 +2454,7 @@ static int download_plane(orbhip_extractor *e, const uint8_t *base, int frame, i
 
 int orbhip_pyramid_level_download(orbhip_extractor *e, int frame, int level, int with_border, uint8_t *dst, int dst_stride)
 {
+    if (level == 0) { if (int rc = ensure_level0(e, nullptr)) return rc; }
     return download_plane(e, e ? e->d_pyr : nullptr, frame, level, with_border, dst, dst_stride);
 }
 
@@ -2366,7 +2463,7 @@ int orbhip_blurred_level_download(orbhip_extractor *e, int frame, int level, uin
     if (e && e->bound && !e->blur_valid && e->last_batch > 0) {
         // the pipeline blurs patches inside the descriptor kernel; the full blurred planes (and their buffer) are
         // produced on request
-        ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+        if (int rc = ensure_level0(e, nullptr)) return rc;
         if (!e->d_blur) ORBHIP_HIP_CHECK(hipMalloc(&e->d_blur, (size_t)e->batch_cap * e->G.frame_bytes));
         hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), e->last_batch), dim3(256), 0, e->stream, e->d_pyr, e->d_blur, e->G,
                            e->d_tiles, e->blurw);

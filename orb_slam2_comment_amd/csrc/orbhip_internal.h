@@ -4,6 +4,7 @@
 
 #include <vector>
 
+struct orbhip_extractor;
 namespace orbhip {
 struct BlurW { int w[7]; };
 struct TileDesc { short level, tx, ty, pad; };
@@ -21,7 +22,8 @@ struct alignas(32) FastCell {
     unsigned short pitch;    // row pitch of the level's padded plane
     short kpx, kpy;          // keypoint = (LDS col + kpx, detection row + kpy) relative to (minBorderX, minBorderY)
     unsigned char sw, sh, a; // sub-image size; a = x0 & 3
-    unsigned char pad[15];
+    unsigned char img;       // 1: src_off / pitch address the caller's image (level 0 without a materialised plane)
+    unsigned char pad[14];
 };
 static_assert(sizeof(FastCell) == 32, "FastCell is one s_load_dwordx8");
 struct FastParams {
@@ -51,6 +53,7 @@ struct PyrLevelTab {
     int src_h, src_pitch;    // source: rows (level-0 copy: REFLECT_101 of the row index), pitch for levels >= 2
     unsigned src_off;        // source ROI inside the frame's pyramid block (levels >= 2)
 };
+int ensure_level0(orbhip_extractor *e, hipStream_t consumer);   // orbhip_extractor.hip
 }  // namespace orbhip
 
 struct orbhip_extractor {
@@ -92,6 +95,13 @@ struct orbhip_extractor {
     orbhip::DiscTab disc_host;
     int *d_disc_off2 = nullptr;     // the same inside the fused descriptor kernel's 43 x 44-byte window tile
     bool blur_valid = false;        // d_blur holds the blurred planes of the last batch
+    // mvImagePyramid[0] on demand (orbhip_extractor_set_lazy_level0)
+    bool lazy_l0 = false;           // the caller's choice
+    bool l0_in_image = false;       // the last extraction read level 0 from the image and did not write the padded plane
+    bool l0_valid = true;           // d_pyr holds the padded level-0 planes of the last batch
+    int cells_stride = 0;           // image row stride the level-0 entries of d_cells2 are built for (0: the padded plane)
+    const uint8_t *src_images = nullptr; int src_stride = 0; size_t src_frame_stride = 0;   // image buffer of the last extraction
+    hipEvent_t ev_l0 = nullptr;
     int *d_disc_off = nullptr;      // [768] byte offsets of the disc pixels inside the staged 31 x 36-byte LDS tile
     float4 *d_patternf = nullptr;   // rBRIEF pattern as floats: (x0, y0, x1, y1) per test
     uint8_t *d_pyrtab = nullptr;    // row / column tables of the pyramid kernels

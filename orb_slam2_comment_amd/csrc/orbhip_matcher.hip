@@ -3163,6 +3163,9 @@ int orbhip_compute_stereo_matches_device(orbhip_matcher *m, orbhip_extractor *le
         return ORBHIP_E_ARG;
     }
     ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    // mvImagePyramid[0] of handles that produce it on demand; this launch is ordered behind the copy
+    if (int rc = ensure_level0(left, m->stream)) return rc;
+    if (right != left) { if (int rc = ensure_level0(right, m->stream)) return rc; }
     StereoGeom G;
     memset(&G, 0, sizeof(G));
     G.nlevels = left->nlevels; G.nrows = left->G.lv[0].h; G.mbf = mbf; G.mb = mb;
@@ -3472,6 +3475,8 @@ int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int
     *nmatches = 0;
     if (nl == 0 || nr == 0) return ORBHIP_OK;
     ORBHIP_HIP_CHECK(hipSetDevice(m->device));
+    if (int rc = ensure_level0(left, nullptr)) return rc;     // mvImagePyramid[0] of handles that produce it on demand
+    if (int rc = ensure_level0(right, nullptr)) return rc;
     // the pyramids were produced on the extractors' streams
     ORBHIP_HIP_CHECK(hipStreamSynchronize(left->stream));
     ORBHIP_HIP_CHECK(hipStreamSynchronize(right->stream));

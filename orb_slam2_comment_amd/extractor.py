@@ -81,6 +81,11 @@ class ORBextractor:
         assert w.shape == (7,)
         check(self._lib.orbhip_extractor_set_blur_kernel(self._h, ptr(w)), "orbhip_extractor_set_blur_kernel")
 
+    def set_lazy_level0(self, on=True):
+        """mvImagePyramid[0] on demand: extractions stop writing the padded level-0 plane (a monocular caller never reads
+        it); the first accessor that needs it builds it from the image buffer of the last extraction."""
+        check(self._lib.orbhip_extractor_set_lazy_level0(self._h, int(on)), "orbhip_extractor_set_lazy_level0")
+
     # -- operator() ---------------------------------------------------------
     def __call__(self, image, mask=None):
         """image: uint8 [rows, cols] (CV_8UC1).  Returns (keypoints[KP_DTYPE], descriptors[n,32])."""

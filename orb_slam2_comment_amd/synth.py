@@ -83,11 +83,13 @@ def synth_frame(seed, W=1241, H=376, n_rect=400, n_disc=200, shift_xy=(0, 0)):
                    shift_xy)
 
 
-def synth_stereo(seed, W=1241, H=376, n_rect=400, n_disc=200):
-    """(left, right) uint8 frames of one layered scene; disparities in [2, 80] px."""
+def synth_stereo(seed, W=1241, H=376, n_rect=400, n_disc=200, shift_xy=(0, 0)):
+    """(left, right) uint8 frames of one layered scene; disparities in [2, 80] px.  `shift_xy` translates the shapes in
+    both eyes (stereo frame t -> t+1)."""
     grid, shapes = _scene(seed, W, H, n_rect, n_disc)
-    left = _render(grid, shapes, W, H, False, (seed << 8) + 1)
-    right = _render(grid, shapes, W, H, True, (seed << 8) + 2)
+    ns = 7 * shift_xy[0] + 13 * shift_xy[1]
+    left = _render(grid, shapes, W, H, False, (seed << 8) + 1 + ns, shift_xy)
+    right = _render(grid, shapes, W, H, True, (seed << 8) + 2 + ns, shift_xy)
     return left, right
 
 

@@ -470,3 +470,80 @@ def test_page_locked_strided_source_is_read_in_place(mods):
             assert_kps_equal(kps[b, :n[b]], okps, "frame %d" % b)
             assert np.array_equal(desc[b, :n[b]], odesc)
         assert np.array_equal(ext.image_pyramid(0, frame=s + 28, with_border=True), ora.level_padded(0))
+
+
+@pytest.mark.parametrize("W,H,nf,scale,nlev", [(1241, 376, 1000, 1.2, 8), (752, 480, 2000, 1.2, 8), (333, 251, 400, 1.3, 5),
+                                               (640, 360, 500, 2.6, 3), (400, 300, 300, 1.2, 1)])
+def test_lazy_level0_is_bit_identical_and_accessors_still_work(mods, W, H, nf, scale, nlev):
+    """orbhip_extractor_set_lazy_level0: level 0 is read from the image (REFLECT_101 by index for the windows of border
+    keypoints), mvImagePyramid[0] is written only when an accessor asks.  Same keypoints, same descriptors, same
+    accessor results; scale 2.6 (level 1 through the general resize kernel, which reads the padded plane) and a one-level
+    pyramid silently keep materialising."""
+    pkg, O = mods
+    ext = pkg.ORBextractor(nf, scale, nlev, 20, 7)
+    ext.set_lazy_level0(True)
+    ora = O.OracleExtractor(nf, scale, nlev, 20, 7)
+    for seed in (31, 32):
+        img = synth_frame(seed, W, H)
+        kps, desc = ext(img)                       # capture, then replay
+        okps, odesc = ora.extract(img)
+        assert_kps_equal(kps, okps, "seed %d" % seed)
+        assert np.array_equal(desc, odesc)
+        l0 = kps[kps["octave"] == 0]
+        if W >= 600:
+            assert ((l0["x"] < 21) | (l0["y"] < 21) | (l0["x"] > W - 23) | (l0["y"] > H - 22)).any(), "no border keypoint in the test image"
+    assert_stagewise_equal(ext, ora, nlev, "lazy")  # level 0 (with border) and its blurred plane are produced now
+    # batch entry, then back to materialising
+    res = ext.extract_batch(np.stack([synth_frame(31, W, H), img]))
+    assert np.array_equal(res[1][1], odesc)
+    assert np.array_equal(ext.image_pyramid(0, frame=1, with_border=True), ora.level_padded(0))
+    ext.set_lazy_level0(False)
+    kps2, desc2 = ext(img)
+    assert_kps_equal(kps2, okps)
+    assert np.array_equal(desc2, odesc)
+    assert_stagewise_equal(ext, ora, nlev, "eager again")
+
+
+def test_lazy_level0_device_entry_with_strides_and_stereo(mods):
+    """Device-pointer entry with a row stride wider than the image and a frame stride with a gap, lazy level 0; then
+    Frame::ComputeStereoMatches on two lazy handles (it needs mvImagePyramid[0] of both: built on demand)."""
+    import torch
+    pkg, O = mods
+    from helpers import synth_stereo
+    Wd, Hd, stride, B = 500, 300, 544, 4
+    fstride = stride * Hd + 4096
+    left, right = synth_stereo(9, Wd, Hd)
+    imgs = [left, right, synth_frame(33, Wd, Hd), left]
+    buf = np.full(B * fstride, 0x5A, np.uint8)
+    for b in range(B):
+        buf[b * fstride: b * fstride + Hd * stride].reshape(Hd, stride)[:, :Wd] = imgs[b]
+    d_img = torch.from_numpy(buf).cuda()
+    ext = pkg.ORBextractor(700, 1.2, 6, 20, 7)
+    ext.set_lazy_level0(True)
+    cap = ext.capacity(Hd, Wd)
+    d_k = torch.zeros((B, cap, 7), dtype=torch.int32, device="cuda"); d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda"); d_s = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ext.set_stream(torch.cuda.current_stream().cuda_stream)
+    ext.extract_batch_device(d_img.data_ptr(), B, Hd, Wd, d_k.data_ptr(), d_d.data_ptr(), cap, d_n.data_ptr(), d_s.data_ptr(),
+                             stride=stride, frame_stride=fstride)
+    torch.cuda.synchronize()
+    n = d_n.cpu().numpy()
+    kps = d_k.cpu().numpy().view(np.uint8).reshape(B, cap, 28).view(pkg.capi.KP_DTYPE).reshape(B, cap)
+    desc = d_d.cpu().numpy()
+    assert int(d_s.abs().sum().item()) == 0
+    ora = O.OracleExtractor(700, 1.2, 6, 20, 7)
+    for b in range(B):
+        okps, odesc = ora.extract(imgs[b])
+        assert_kps_equal(kps[b, :n[b]], okps, "frame %d" % b)
+        assert np.array_equal(desc[b, :n[b]], odesc)
+    assert np.array_equal(ext.image_pyramid(0, frame=3, with_border=True), ora.level_padded(0))
+    ext.set_stream(0)
+    # stereo: two lazy handles against two eager ones
+    res = []
+    for lazy in (True, False):
+        eL, eR = pkg.ORBextractor(700, 1.2, 6, 20, 7), pkg.ORBextractor(700, 1.2, 6, 20, 7)
+        eL.set_lazy_level0(lazy); eR.set_lazy_level0(lazy)
+        kl, dl = eL(left); kr, dr = eR(right)
+        res.append(pkg.ORBmatcher().ComputeStereoMatches(eL, eR, kl, dl, kr, dr, 386.1448, 386.1448 / 718.856))
+    assert res[0][0] == res[1][0] and res[0][0] > 50
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])

@@ -99,3 +99,20 @@ def test_bench_self_launches_two_ranks_gloo_dry_run():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["gather_verified"] is True
     assert out["config"]["pairs_per_rank"] == 4 and out["config"]["parallelism"] == "pair-sharded x2"
+
+
+def test_bench_default_is_configs3_global_batch_512_at_8_ranks():
+    """`python bench.py --gpus 8` runs BASELINE.json configs[3] as written: a global batch of 512 frames, 64 frames = 32
+    (last, cur) pairs per GPU (strong scaling over N); --frames-per-gpu fixes the per-GPU batch instead (weak)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dist-backend", "gloo", "--dry-run",
+                        "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert out["n_gpus"] == 8 and out["gather_verified"] is True and out["scaling"] == "strong"
+    assert out["config"]["global_batch"] == 512 and out["config"]["frames_per_gpu_per_step"] == 64
+    assert out["config"]["pairs_per_rank"] == 32
