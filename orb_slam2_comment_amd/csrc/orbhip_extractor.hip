@@ -496,8 +496,12 @@ __device__ __forceinline__ unsigned long long stamp_now()
     return t;
 }
 
+#ifndef ORBHIP_FAST_WAVES
+#define ORBHIP_FAST_WAVES 6   // resident waves per SIMD: 258-263 us per 172 frames alone against 266-269 at 8; the contended headline does not
+                              // move outside its run-to-run band (tools/ab_build.sh)
+#endif
 template <int SW, bool STAMPS = false>
-__global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, const FastCell *__restrict__ cells,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORBHIP_FAST_WAVES, ORBHIP_FAST_WAVES))) void k_fast_cells(const uint8_t *__restrict__ pyr, const FastCell *__restrict__ cells,
                                                     int *__restrict__ cell_cnt, uint32_t *__restrict__ cell_kp,
                                                     FastParams P, const uint8_t *__restrict__ images, size_t frame_stride)
 {
@@ -1266,13 +1270,14 @@ constexpr int kWinWords = kWinRows * kWinDw + 7;   // + the dwords the last colu
 constexpr int kHPairs = 22, kHGroups = 10;    // row-pass results: 22 pair-rows x 10 groups of 4 columns (uint4 each)
 
 #ifndef ORBHIP_DESC_WAVES
-#define ORBHIP_DESC_WAVES 6   // resident waves per SIMD the register allocation is held to (78 VGPRs; 4: 232 k, 5: 240-244 k, 6: 235-246 k frames/s in tools/ab_build.sh)
+#define ORBHIP_DESC_WAVES 5   // resident waves per SIMD (the allocation is padded to 81 VGPRs; the kernel needs 66).  One pipeline alone is fastest at 6-7
+                              // (175 vs 188 us per 172 frames); three concurrent pipelines at 5: 244-245 k frames/s in both rounds of
+                              // tools/ab_build.sh against 235-245 k (6) and 236 k (7) -- fewer descriptor waves leave the other pipelines room
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBHIP_DESC_WAVES, ORBHIP_DESC_WAVES))) void k_describe_fused(const uint8_t *__restrict__ pyr, PyrGeom G,
                                                         const uint32_t *__restrict__ sel_kp,
                                                         const int *__restrict__ sel_cnt,
-                                                        const DiscTab *__restrict__ disc,
-                                                        const int *__restrict__ disc_off,
+                                                        const int *__restrict__ desc_tab,
                                                         const float4 *__restrict__ patternf,
                                                         orbhip_keypoint *__restrict__ out_kp,
                                                         uint8_t *__restrict__ out_desc, int cap,
@@ -1286,15 +1291,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBHIP_DESC
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bx, b;
     xcd_remap(bx, b);
-    uint32_t u2[6], v2[6];
+    // orientation disc as aligned dwords of the window tile: the 749 disc pixels sit in 213 (row, 4-column) chunks, four
+    // per lane; per chunk the dword index inside the tile and the signed byte weights u (column offset) and v (row offset)
+    // of its four pixels, 0 outside the disc
+    int cw[4], uw[4], vw[4];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { u2[k] = disc->u2[k * 64 + lane]; v2[k] = disc->v2[k * 64 + lane]; }
+    for (int k = 0; k < 4; ++k) { cw[k] = desc_tab[k * 64 + lane]; uw[k] = desc_tab[256 + k * 64 + lane]; vw[k] = desc_tab[512 + k * 64 + lane]; }
     float4 pat[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) pat[j] = patternf[j * 64 + lane];
-    int dl[12];   // byte offset of this lane's 12 disc pixels inside the window tile: (v + 21) * 44 + (u + 21)
-#pragma unroll
-    for (int k = 0; k < 12; ++k) dl[k] = disc_off[k * 64 + lane];
     const int *cnts = sel_cnt + b * ORBHIP_MAX_LEVELS;
     int total = 0;
     for (int l = 0; l < G.nlevels; ++l) total += cnts[l];
@@ -1376,18 +1381,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBHIP_DESC
     }
     __builtin_amdgcn_wave_barrier();
     // ---- moments ----
+    // sum u * I = sum u * (I - 128) because the weights of the disc sum to zero: the pixels become signed bytes (xor
+    // 0x80) and a chunk costs two v_dot4c_i32_i8
     int m10 = 0, m01 = 0;
-    {
-        const uint8_t *d8 = reinterpret_cast<const uint8_t *>(win);
-        int pix[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) pix[k] = d8[dl[k]];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const uint32_t p2 = (uint32_t)pix[2 * k] | ((uint32_t)pix[2 * k + 1] << 16);
-            m10 = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, p2), __builtin_bit_cast(i16x2_t, u2[k]), m10, false);
-            m01 = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, p2), __builtin_bit_cast(i16x2_t, v2[k]), m01, false);
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int d = (int)(win[cw[k]] ^ 0x80808080u);
+        m10 = __builtin_amdgcn_sdot4(d, uw[k], m10, false);
+        m01 = __builtin_amdgcn_sdot4(d, vw[k], m01, false);
     }
     // ---- row pass: 7-tap sums of window rows, two rows per item ----
 #pragma unroll 1
@@ -1981,9 +1982,9 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         // IC_Angle + the 7x7 blur of the keypoint's patch + rBRIEF in one kernel: no blurred plane exists unless
         // orbhip_blurred_level_download asks for one
         const dim3 grid((G.kp_cap_total + 4 * kDescPerWave - 1) / (4 * kDescPerWave), batch);
-        hipLaunchKernelGGL(k_describe_fused, grid, dim3(256), 0, s, b_pyr, G, b_sel, b_sel_cnt, e->d_disc, e->d_disc_off2,
+        hipLaunchKernelGGL(k_describe_fused, grid, dim3(256), 0, s, b_pyr, G, b_sel, b_sel_cnt, e->d_desc_tab,
                            e->d_patternf, d_kps, d_desc, cap, d_n, status, kDescPerWave, e->blurw,
-                           reinterpret_cast<const uint32_t *>(e->d_disc_off2 + 768), lazy ? d_images : (const uint8_t *)nullptr, stride,
+                           reinterpret_cast<const uint32_t *>(e->d_desc_tab + 768), lazy ? d_images : (const uint8_t *)nullptr, stride,
                            frame_stride);
     }
     if (prof) { (void)hipEventRecord(ev[4], s); e->prof_calls++; }
@@ -2046,36 +2047,40 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
         return ORBHIP_E_HIP;
     }
     e->stream = e->own_stream;
-    // disc offsets in the reference's traversal order (order is irrelevant for integer sums): pixel k of lane l is entry
-    // k*64 + l; padding entries (u = v = 0) re-read the centre pixel with weight 0
-    DiscTab &dt = e->disc_host; memset(&dt, 0, sizeof(dt));
-    int nd = 0;
-    signed char du[768], dv[768];
-    memset(du, 0, sizeof(du)); memset(dv, 0, sizeof(dv));
-    auto put = [&](int u, int v) { du[nd] = (signed char)u; dv[nd] = (signed char)v; ++nd; };
-    for (int u = -kHalfPatch; u <= kHalfPatch; ++u) put(u, 0);
-    for (int vv = 1; vv <= kHalfPatch; ++vv) {
-        int d = e->umax[vv];
-        for (int u = -d; u <= d; ++u) { put(u, vv); put(u, -vv); }
-    }
-    if (nd != 749) { set_error("disc table has %d entries", nd); orbhip_extractor_destroy(e); return ORBHIP_E_ARG; }
-    for (int k = 0; k < 12; ++k)
-        for (int l = 0; l < 64; ++l) { dt.u[k * 64 + l] = du[k * 64 + l]; dt.v[k * 64 + l] = dv[k * 64 + l]; }
-    for (int k = 0; k < 6; ++k)
-        for (int l = 0; l < 64; ++l) {   // int16 pairs (pixel 2k, pixel 2k+1) of lane l
-            dt.u2[k * 64 + l] = (uint32_t)(uint16_t)(short)du[(2 * k) * 64 + l] | ((uint32_t)(uint16_t)(short)du[(2 * k + 1) * 64 + l] << 16);
-            dt.v2[k * 64 + l] = (uint32_t)(uint16_t)(short)dv[(2 * k) * 64 + l] | ((uint32_t)(uint16_t)(short)dv[(2 * k + 1) * 64 + l] << 16);
+    // orientation disc (IC_Angle, :77-104: rows v = -15 .. 15, columns |u| <= umax[|v|]) cut into the aligned dwords of the
+    // descriptor kernel's window tile (row stride 11 dwords, disc centre at row 21, byte column 21): chunk t = (row, dword);
+    // lane l owns chunks l, 64 + l, 128 + l, 192 + l (consecutive lanes read consecutive dwords); integer sums do not
+    // depend on the order
+    int dtab[768 + 64];
+    memset(dtab, 0, sizeof(dtab));
+    {
+        int nchunk = 0, npix = 0;
+        for (int v = -kHalfPatch; v <= kHalfPatch; ++v) {
+            const int d = e->umax[v < 0 ? -v : v];
+            for (int c = (21 - d) / 4; c <= (21 + d) / 4; ++c) {
+                uint32_t uwt = 0, vwt = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const int u = 4 * c + k - 21;
+                    if (u < -d || u > d) continue;
+                    uwt |= (uint32_t)(uint8_t)(signed char)u << (8 * k);
+                    vwt |= (uint32_t)(uint8_t)(signed char)v << (8 * k);
+                    ++npix;
+                }
+                if (nchunk < 256) {
+                    dtab[nchunk] = (v + 21) * 11 + c;
+                    dtab[256 + nchunk] = (int)uwt;
+                    dtab[512 + nchunk] = (int)vwt;
+                }
+                ++nchunk;
+            }
         }
+        if (npix != 749 || nchunk > 256) { set_error("disc table: %d pixels in %d chunks", npix, nchunk); orbhip_extractor_destroy(e); return ORBHIP_E_ARG; }
+    }
     float patf[1024];
     for (int t = 0; t < 1024; ++t) patf[t] = (float)orbhip_rbrief_pattern[t];
-    if (hipMalloc(&e->d_disc, sizeof(DiscTab)) != hipSuccess || hipMalloc(&e->d_patternf, sizeof(patf)) != hipSuccess ||
-        hipMalloc(&e->d_disc_off, 768 * sizeof(int)) != hipSuccess || hipMalloc(&e->d_disc_off2, (768 + 64) * sizeof(int)) != hipSuccess) {
+    if (hipMalloc(&e->d_patternf, sizeof(patf)) != hipSuccess || hipMalloc(&e->d_desc_tab, sizeof(dtab)) != hipSuccess) {
         set_error("hipMalloc failed"); orbhip_extractor_destroy(e); return ORBHIP_E_HIP;
     }
-    int dloff[768];   // byte offset of every disc pixel inside the staged 31 x 36-byte tile; padding entries read (0, 0) with weight 0
-    for (int t = 0; t < 768; ++t) dloff[t] = ((int)dv[t] + kHalfPatch) * 36 + ((int)du[t] + kHalfPatch);
-    int dloff2[768 + 64];  // the same inside the fused kernel's 43 x 44-byte window tile, then the row-pass item table
-    for (int t = 0; t < 768; ++t) dloff2[t] = ((int)dv[t] + 21) * 44 + ((int)du[t] + 21);
     {
         // A descriptor test samples the blurred patch at (round(x*sin + y*cos), round(x*cos - y*sin)) of a pattern point
         // (x, y): |offset component| <= round(max radius) and offset length <= max radius + sqrt(0.5).  Patch row r'
@@ -2098,11 +2103,9 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
             set_error("row-pass item table overflow (%d)", (int)items.size()); orbhip_extractor_destroy(e); return ORBHIP_E_ARG;
         }
         while (items.size() < 192) items.push_back(items[0]);   // idle slots repeat an item (same value written twice)
-        for (int l = 0; l < 64; ++l) dloff2[768 + l] = items[l] | (items[64 + l] << 8) | (items[128 + l] << 16);
+        for (int l = 0; l < 64; ++l) dtab[768 + l] = items[l] | (items[64 + l] << 8) | (items[128 + l] << 16);
     }
-    if (hipMemcpyAsync(e->d_disc_off, dloff, sizeof(dloff), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
-        hipMemcpyAsync(e->d_disc_off2, dloff2, sizeof(dloff2), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
-        hipMemcpyAsync(e->d_disc, &dt, sizeof(dt), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+    if (hipMemcpyAsync(e->d_desc_tab, dtab, sizeof(dtab), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
         hipMemcpyAsync(e->d_patternf, patf, sizeof(patf), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
         hipStreamSynchronize(e->stream) != hipSuccess) {
         set_error("upload of the orientation / rBRIEF tables failed"); orbhip_extractor_destroy(e); return ORBHIP_E_HIP;
@@ -2118,7 +2121,7 @@ void orbhip_extractor_destroy(orbhip_extractor *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_geometry(e);
     free_batch(e);
-    (void)hipFree(e->d_disc); (void)hipFree(e->d_patternf); (void)hipFree(e->d_disc_off); (void)hipFree(e->d_disc_off2); (void)hipFree(e->d_img); (void)hipFree(e->d_okp); (void)hipFree(e->d_odesc); (void)hipFree(e->d_on);
+    (void)hipFree(e->d_patternf); (void)hipFree(e->d_desc_tab); (void)hipFree(e->d_img); (void)hipFree(e->d_okp); (void)hipFree(e->d_odesc); (void)hipFree(e->d_on);
     if (e->h_in) (void)hipHostFree(e->h_in);
     if (e->h_out) (void)hipHostFree(e->h_out);
     for (hipEvent_t v : e->ev) (void)hipEventDestroy(v);

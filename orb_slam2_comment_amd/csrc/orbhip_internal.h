@@ -31,9 +31,6 @@ struct FastParams {
     int ncells_total, slot_cap, ini_th, min_th, img_words, score_words;
     int dev;   // development builds only: timing floors / stamped kernel
 };
-// the 749 disc offsets of IC_Angle, zero padded to 12 x 64 (pixel k of lane l = entry k*64 + l): signed (u, v) and the
-// int16 pairs (pixel 2k | pixel 2k+1 << 16) the moment dot products take
-struct DiscTab { signed char u[768], v[768]; uint32_t u2[384], v2[384]; };
 // Tables of the pyramid kernels (k_pyr_base / k_pyr_rows): a wavefront owns kPyrRows padded destination rows (its row
 // records come through scalar loads) and one destination dword (resize) or 16-byte group (level-0 copy) per lane.
 struct PyrRow { int s0, s1; uint32_t B0, B1; };        // source rows of a destination row; Q11 row coefficients << 12
@@ -91,9 +88,7 @@ struct orbhip_extractor {
     orbhip::FastCell *d_cells2 = nullptr;
     orbhip::FastParams fast_params;
     orbhip::TileDesc *d_tiles = nullptr;
-    orbhip::DiscTab *d_disc = nullptr;
-    orbhip::DiscTab disc_host;
-    int *d_disc_off2 = nullptr;     // the same inside the fused descriptor kernel's 43 x 44-byte window tile
+    int *d_desc_tab = nullptr;      // descriptor kernel tables: disc chunks {dword index, u weights, v weights}[4][64], row-pass items[64]
     bool blur_valid = false;        // d_blur holds the blurred planes of the last batch
     // mvImagePyramid[0] on demand (orbhip_extractor_set_lazy_level0)
     bool lazy_l0 = false;           // the caller's choice
@@ -102,7 +97,6 @@ struct orbhip_extractor {
     int cells_stride = 0;           // image row stride the level-0 entries of d_cells2 are built for (0: the padded plane)
     const uint8_t *src_images = nullptr; int src_stride = 0; size_t src_frame_stride = 0;   // image buffer of the last extraction
     hipEvent_t ev_l0 = nullptr;
-    int *d_disc_off = nullptr;      // [768] byte offsets of the disc pixels inside the staged 31 x 36-byte LDS tile
     float4 *d_patternf = nullptr;   // rBRIEF pattern as floats: (x0, y0, x1, y1) per test
     uint8_t *d_pyrtab = nullptr;    // row / column tables of the pyramid kernels
     orbhip::PyrLevelTab ptab[ORBHIP_MAX_LEVELS];
