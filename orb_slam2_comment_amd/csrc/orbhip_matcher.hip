@@ -86,6 +86,36 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
 }
 
+// The smallest keys of a list whose entries are spread over the lanes, in ascending order, EXACTLY: every lane hands in
+// its two smallest keys (a1 < a2, ~0 = none) and whether it holds more than those two.  Minimum after minimum is
+// extracted; once a lane has given both of its keys and still holds others, a later minimum could be one of those, so
+// the extraction stops there.  Keys are unique.  Returns the number of keys written to head[] (wave-uniform, <= kHeadMax);
+// *complete = the list has no further key (the extraction ran dry, not into the stop condition or the limit).
+constexpr int kHeadMax = 8;
+__device__ __forceinline__ int wave_sorted_head(unsigned long long a1, unsigned long long a2, bool more,
+                                                unsigned long long (&head)[kHeadMax], bool *complete)
+{
+    int given = 0, hl = 0;
+    bool stop = false, dry = false;
+#pragma unroll
+    for (int k = 0; k < kHeadMax; ++k) {
+        head[k] = ~0ull;
+        if (stop || dry) continue;          // wave-uniform
+        const unsigned long long c = given == 0 ? a1 : (given == 1 ? a2 : ~0ull);
+        const unsigned long long g = wave_min_u64(c);
+        if (g == ~0ull) { dry = true; continue; }
+        head[k] = g;
+        hl = k + 1;
+        const bool mine = c == g;
+        if (mine) ++given;
+        stop = __any(mine && given == 2 && more) != 0;
+    }
+    // a lane that still holds an unextracted tracked key, or more keys than it tracks, means the list goes on
+    const bool rest = (given == 0 && a1 != ~0ull) || (given <= 1 && a2 != ~0ull) || more;
+    *complete = !__any(rest);
+    return hl;
+}
+
 // Visiting-order key of every train keypoint, (posX*48+posY) << 20 | index, or kNoCell when PosInGrid rejects it
 // (k_best_in_window scans the frame with it).
 __global__ void k_grid_order(DevFrame F, uint32_t *__restrict__ ord, Batch B)
@@ -182,7 +212,8 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const int *__
                                                        const uint8_t *__restrict__ qdesc, int nq,
                                                        unsigned long long *__restrict__ cand,
                                                        unsigned long long *__restrict__ ccand,
-                                                       int *__restrict__ cnt, int stride, int use_ur, Batch B)
+                                                       int *__restrict__ cnt, int stride, int use_ur, Batch B,
+                                                       const uint8_t *__restrict__ taken, int max_dist)
 {
     __shared__ unsigned long long stage[4][64];
     __shared__ int spos[4][64];
@@ -198,6 +229,7 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const int *__
     cand += (size_t)pair * B.qcap * stride;
     ccand += (size_t)pair * B.qcap * kCompact;
     cnt += (size_t)pair * B.qcap;
+    if (taken) taken += (size_t)pair * B.cap;
     if (B.nq_dev) nq = min(B.nq_dev[pair], B.qcap);
     const int qi = blockIdx.x * 4 + wv;
     if (qi >= nq) return;
@@ -222,6 +254,8 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const int *__
     unsigned long long *out = cand + (size_t)qi * stride;
     const int ncy = nMaxCellY - nMinCellY + 1, ncell = (nMaxCellX - nMinCellX + 1) * ncy;
     int total = 0;
+    unsigned long long b1 = ~0ull, b2 = ~0ull;   // this lane's two smallest keys among candidates not taken on entry
+    int nb = 0;                                  // ... out of how many
     // a column of the window is a contiguous run of cells (cell = ix * 48 + iy), so its records are one contiguous CSR
     // range: lane = window column, range = [start[ix*48 + y0], start[ix*48 + y1 + 1])
     const int ncol = nMaxCellX - nMinCellX + 1;
@@ -263,12 +297,19 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const int *__
                 const int dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w) +
                                  __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
                 key = ((unsigned long long)dist << 32) | R.key;
+                // searches that take the best candidate alone (no second best, no ratio test) never look past the first
+                // free entry, and an entry beyond their acceptance threshold can only mean "no match": it need not be listed
+                ok = ok && dist <= max_dist;
             }
             const unsigned long long bal = __ballot(ok);
             if (ok) {
                 const int pos = total + __popcll(bal & ((1ull << lane) - 1ull));
                 out[pos] = key;
                 if (pos < 64) stage[wv][pos] = key;
+                if (!(taken && taken[key & 0xfffffu])) {
+                    if (key < b1) { b2 = b1; b1 = key; } else if (key < b2) b2 = key;
+                    ++nb;
+                }
             }
             total += __popcll(bal);
         }
@@ -289,8 +330,23 @@ __global__ __launch_bounds__(256) void k_window_search(DevFrame F, const int *__
         }
         if (lane < total) ccand[(size_t)qi * kCompact + rank] = v;
         if (lane == 0) cnt[qi] = total;
-    } else if (lane == 0) {
-        cnt[qi] = -total;
+    } else {
+        // more than 64 candidates: the list stays unsorted in `cand`; the first (up to kHeadMax) keys of its sorted order
+        // among the candidates not taken on entry go to the head of the compact row -- {keys[8], count | complete << 8} --
+        // so the resolve walks a sorted head like it does for short lists and only scans the list when the head runs out
+        if (total > 64) {
+            unsigned long long head[kHeadMax];
+            bool complete;
+            const int hl = wave_sorted_head(b1, b2, nb > 2, head, &complete);
+            if (lane < kHeadMax) {
+                unsigned long long v = head[0];
+#pragma unroll
+                for (int k = 1; k < kHeadMax; ++k) if (lane == k) v = head[k];
+                ccand[(size_t)qi * kCompact + lane] = v;
+            }
+            if (lane == 0) ccand[(size_t)qi * kCompact + kHeadMax] = (unsigned long long)hl | (complete ? 0x100ull : 0ull);
+        }
+        if (lane == 0) cnt[qi] = -total;
     }
 }
 
@@ -1036,7 +1092,19 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     if (lc_on) {
         for (int i = tid; i < nq; i += T) {
             const int c = S.q_cnt[i];
-            if (c <= 0) continue;
+            if (c == 0) continue;
+            if (c < 0) {   // unsorted list: the window search left the head of its sorted order in the compact row
+                if (ccand && S.lcn >= kHeadMax) {
+                    const unsigned long long *hrow = ccand + (size_t)i * kCompact;
+#pragma unroll
+                    for (int e = 0; e < kHeadMax; ++e) {
+                        const unsigned long long h = hrow[e];
+                        S.lc[i * (S.lcn + 1) + e] = ((uint32_t)(h >> 32) << 20) | (uint32_t)(h & 0xfffffu);
+                    }
+                    S.lc[i * (S.lcn + 1) + S.lcn] = (uint32_t)hrow[kHeadMax];
+                }
+                continue;
+            }
             if (i != tid || !ccand) {
                 const unsigned long long *l0 = ccand ? ccand + (size_t)i * kCompact : cand + (size_t)i * stride;
 #pragma unroll
@@ -1057,59 +1125,63 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
     int *wl_count = nullptr;
     int *claim = holder;                 // where an accepted, observed query files its claim
     bool claims_rebuilt = false;         // mode 1: the claims are rebuilt from scratch every round
-    auto step = [&](int i) -> bool {
-        const int c = S.q_cnt[i];
+    // pick: best (and, mode 1, second best) available entry of query i's list.  A sorted list (<= 64 candidates) is walked
+    // by the thread that owns the query; an unsorted one (more candidates: wide windows) by the whole wavefront, lanes over
+    // the entries (step_group below).
+    auto pick_sorted = [&](int i, int c, unsigned long long &k1, unsigned long long &k2) {
+        const unsigned long long *list = ccand ? ccand + (size_t)i * kCompact : cand + (size_t)i * stride;
+        const uint32_t *lrow = S.lc + i * (S.lcn + 1);
+        auto entry = [&](int e) -> unsigned long long {
+            if (e >= c) return ~0ull;
+            if (!GS && e < S.lcn) { const uint32_t w = lrow[e]; return ((unsigned long long)(w >> 20) << 32) | (w & 0xfffffu); }
+            return list[e];
+        };
+        // four entries per trip: their eight LDS reads (taken, holder) are in flight together
+        int e1 = mode == 1 ? 0 : cur1[i];
+        while (e1 < c) {
+            const unsigned long long v0 = entry(e1), v1 = entry(e1 + 1), v2 = entry(e1 + 2), v3 = entry(e1 + 3);
+            const bool a0 = !held_by_smaller((int)(v0 & 0xfffffu), i);
+            const bool a1 = v1 != ~0ull && !held_by_smaller((int)(v1 & 0xfffffu), i);
+            const bool a2 = v2 != ~0ull && !held_by_smaller((int)(v2 & 0xfffffu), i);
+            const bool a3 = v3 != ~0ull && !held_by_smaller((int)(v3 & 0xfffffu), i);
+            if (a0) { k1 = v0; break; }
+            if (a1) { k1 = v1; e1 += 1; break; }
+            if (a2) { k1 = v2; e1 += 2; break; }
+            if (a3) { k1 = v3; e1 += 3; break; }
+            e1 += 4;
+        }
+        e1 = min(e1, c);
+        if (mode != 1) cur1[i] = (unsigned short)e1;
+        if (mode == 1 && e1 < c) {
+            for (int e2 = e1 + 1; e2 < c; ++e2) {
+                const unsigned long long v = entry(e2);
+                if (!held_by_smaller((int)(v & 0xfffffu), i)) { k2 = v; break; }
+            }
+        }
+    };
+    auto pick_unsorted_wave = [&](int i, int len, unsigned long long &k1, unsigned long long &k2) {   // every lane, same (i, len)
+        const unsigned long long *list = cand + (size_t)i * stride;
+        unsigned long long a1 = ~0ull, a2 = ~0ull;
+        for (int e = (int)(threadIdx.x & 63); e < len; e += 64) {
+            const unsigned long long v = list[e];
+            if (held_by_smaller((int)(v & 0xfffffu), i)) continue;
+            if (v < a1) { a2 = a1; a1 = v; } else if (v < a2) a2 = v;
+        }
+        k1 = wave_min_u64(a1);
+        k2 = mode == 1 ? wave_min_u64(a1 == k1 ? a2 : a1) : ~0ull;   // keys are unique (the slot is part of the key)
+    };
+    auto commit = [&](int i, unsigned long long k1, unsigned long long k2) -> bool {
         int newc = -1;
-        if (c != 0) {
-            const unsigned long long *list = (c > 0 && ccand) ? ccand + (size_t)i * kCompact : cand + (size_t)i * stride;
-            unsigned long long k1 = ~0ull, k2 = ~0ull;
-            if (c > 0) {   // sorted: monotone cursors
-                const uint32_t *lrow = S.lc + i * (S.lcn + 1);
-                auto entry = [&](int e) -> unsigned long long {
-                    if (e >= c) return ~0ull;
-                    if (!GS && e < S.lcn) { const uint32_t w = lrow[e]; return ((unsigned long long)(w >> 20) << 32) | (w & 0xfffffu); }
-                    return list[e];
-                };
-                // four entries per trip: their eight LDS reads (taken, holder) are in flight together
-                int e1 = mode == 1 ? 0 : cur1[i];
-                while (e1 < c) {
-                    const unsigned long long v0 = entry(e1), v1 = entry(e1 + 1), v2 = entry(e1 + 2), v3 = entry(e1 + 3);
-                    const bool a0 = !held_by_smaller((int)(v0 & 0xfffffu), i);
-                    const bool a1 = v1 != ~0ull && !held_by_smaller((int)(v1 & 0xfffffu), i);
-                    const bool a2 = v2 != ~0ull && !held_by_smaller((int)(v2 & 0xfffffu), i);
-                    const bool a3 = v3 != ~0ull && !held_by_smaller((int)(v3 & 0xfffffu), i);
-                    if (a0) { k1 = v0; break; }
-                    if (a1) { k1 = v1; e1 += 1; break; }
-                    if (a2) { k1 = v2; e1 += 2; break; }
-                    if (a3) { k1 = v3; e1 += 3; break; }
-                    e1 += 4;
-                }
-                e1 = min(e1, c);
-                if (mode != 1) cur1[i] = (unsigned short)e1;
-                if (mode == 1 && e1 < c) {
-                    for (int e2 = e1 + 1; e2 < c; ++e2) {
-                        const unsigned long long v = entry(e2);
-                        if (!held_by_smaller((int)(v & 0xfffffu), i)) { k2 = v; break; }
-                    }
-                }
-            } else {       // unsorted (more than 64 candidates): smallest and second smallest available key
-                for (int e = 0; e < -c; ++e) {
-                    const unsigned long long v = list[e];
-                    if (held_by_smaller((int)(v & 0xfffffu), i)) continue;
-                    if (v < k1) { k2 = k1; k1 = v; } else if (v < k2) k2 = v;
-                }
+        if (k1 != ~0ull) {
+            const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xfffffu);
+            bool acc = bestDist <= th_accept;
+            if (acc && mode == 1) {
+                const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
+                const int bestLevel = S.t_oct[bestIdx];
+                const int bestLevel2 = k2 == ~0ull ? -1 : (int)S.t_oct[(int)(k2 & 0xfffffu)];
+                if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) acc = false;
             }
-            if (k1 != ~0ull) {
-                const int bestDist = (int)(k1 >> 32), bestIdx = (int)(k1 & 0xfffffu);
-                bool acc = bestDist <= th_accept;
-                if (acc && mode == 1) {
-                    const int bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 32);
-                    const int bestLevel = S.t_oct[bestIdx];
-                    const int bestLevel2 = k2 == ~0ull ? -1 : (int)S.t_oct[(int)(k2 & 0xfffffu)];
-                    if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) acc = false;
-                }
-                if (acc) newc = bestIdx;
-            }
+            if (acc) newc = bestIdx;
         }
         const bool changed = newc != S.choice[i];
         if (!changed && !claims_rebuilt) return false;
@@ -1125,6 +1197,113 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
         }
         return changed;
     };
+    // One deferred-acceptance / fixed-point step for the queries of a whole wavefront (lane: query i, `valid` false for
+    // idle lanes; every lane of the wavefront must call).  Queries with unsorted lists are taken one after the other by
+    // the whole wavefront -- a single thread re-scanning a 300-entry list in HBM on every step is what made wide windows
+    // slow (th = 60: 293 us, th = 100: 556 us per 32 pairs).
+    // Unsorted lists with a sorted head in LDS (the LDS variant with list heads; `head_on`): the owner thread walks the
+    // head -- kHeadMax keys in list order, candidates taken on entry left out -- like a sorted list.  Frame search: the
+    // cursor is monotone, and when the head runs out before the list does the wavefront refills it with the next keys
+    // behind the last one (one scan of the list per kHeadMax steps instead of one per step).  Map-point search: first and
+    // second free entry of the initial head; if the head cannot tell (not both found and the list goes on) the wavefront
+    // scans the whole list.  Returns "needs the wavefront".
+    const bool head_on = lc_on && S.lcn >= kHeadMax && ccand != nullptr;
+    auto expand = [](uint32_t w) -> unsigned long long { return ((unsigned long long)(w >> 20) << 32) | (w & 0xfffffu); };
+    auto head_walk = [&](int i, unsigned long long &k1, unsigned long long &k2) -> bool {
+        const uint32_t *lrow = S.lc + i * (S.lcn + 1);
+        const uint32_t meta = lrow[S.lcn];
+        const int hl = (int)(meta & 0xffu);
+        const bool complete = (meta & 0x100u) != 0;
+        if (mode != 1) {
+            int e = cur1[i];
+            while (e < hl) {
+                const uint32_t w = lrow[e];
+                if (!held_by_smaller((int)(w & 0xfffffu), i)) { k1 = expand(w); break; }
+                ++e;
+            }
+            cur1[i] = (unsigned short)e;
+            return e >= hl && !complete;
+        }
+        k1 = k2 = ~0ull;
+        for (int e = 0; e < hl; ++e) {
+            const uint32_t w = lrow[e];
+            if (held_by_smaller((int)(w & 0xfffffu), i)) continue;
+            if (k1 == ~0ull) k1 = expand(w); else { k2 = expand(w); break; }
+        }
+        return k2 == ~0ull && !complete;
+    };
+    auto refill_head_wave = [&](int i, int len) {   // every lane, same (i, len): the next keys behind the head's last one
+        const int lane = (int)(threadIdx.x & 63);
+        uint32_t *lrow = S.lc + i * (S.lcn + 1);
+        const int hl = (int)(lrow[S.lcn] & 0xffu);
+        // the head's last key in full: the LDS copy holds (distance, slot); the cell bits of the key are the slot's grid
+        // cell (PosInGrid, src/Frame.cc:382-392, the expressions of the grid build)
+        unsigned long long cursor = 0ull;
+        if (hl > 0) {
+            const uint32_t w = lrow[hl - 1];
+            const int slot = (int)(w & 0xfffffu);
+            const orbhip_keypoint kp = F.keys[slot];
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, F.min_x), F.inv_w));
+            const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, F.min_y), F.inv_h));
+            cursor = ((unsigned long long)(w >> 20) << 32) | ((unsigned long long)(uint32_t)(px * GRID_ROWS + py) << 20) | (uint32_t)slot;
+        }
+        const unsigned long long *list = cand + (size_t)i * stride;
+        unsigned long long a1 = ~0ull, a2 = ~0ull;
+        int na = 0;
+        for (int e = lane; e < len; e += 64) {
+            const unsigned long long v = list[e];
+            if ((hl > 0 && v <= cursor) || S.taken[(int)(v & 0xfffffu)]) continue;
+            if (v < a1) { a2 = a1; a1 = v; } else if (v < a2) a2 = v;
+            ++na;
+        }
+        unsigned long long head[kHeadMax];
+        bool complete;
+        const int nh = wave_sorted_head(a1, a2, na > 2, head, &complete);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < kHeadMax) {
+            unsigned long long v = head[0];
+#pragma unroll
+            for (int k = 1; k < kHeadMax; ++k) if (lane == k) v = head[k];
+            lrow[lane] = ((uint32_t)(v >> 32) << 20) | (uint32_t)(v & 0xfffffu);
+        }
+        if (lane == 0) lrow[S.lcn] = (uint32_t)nh | (complete ? 0x100u : 0u);
+        __builtin_amdgcn_wave_barrier();
+    };
+    // One deferred-acceptance / fixed-point step for the queries of a whole wavefront (lane: query i, `valid` false for
+    // idle lanes; every lane of the wavefront must call).  What an unsorted list needs from the whole wavefront -- a
+    // refill of its head, or a scan -- is done for one query after the other, lanes over the list entries: a single
+    // thread re-scanning a 300-entry list in HBM on every step is what made wide windows slow (th = 60: 293 us,
+    // th = 100: 556 us per 32 pairs).
+    auto step_group = [&](int i, bool valid) -> bool {
+        const int lane = (int)(threadIdx.x & 63);
+        const int c = valid ? S.q_cnt[i] : 0;
+        unsigned long long k1 = ~0ull, k2 = ~0ull;
+        if (c > 0) pick_sorted(i, c, k1, k2);
+        bool need = c < 0;
+        if (need && head_on) need = head_walk(i, k1, k2);
+        if (head_on && mode != 1) {
+            for (;;) {
+                unsigned long long longs = __ballot(need);
+                if (!longs) break;
+                while (longs) {
+                    const int src = __ffsll((long long)longs) - 1;
+                    refill_head_wave(__builtin_amdgcn_readlane(i, src), -__builtin_amdgcn_readlane(c, src));
+                    longs &= longs - 1;
+                }
+                if (need) { cur1[i] = 0; need = head_walk(i, k1, k2); }
+            }
+        } else {
+            unsigned long long longs = __ballot(need);
+            while (longs) {
+                const int src = __ffsll((long long)longs) - 1;
+                unsigned long long t1, t2;
+                pick_unsorted_wave(__builtin_amdgcn_readlane(i, src), -__builtin_amdgcn_readlane(c, src), t1, t2);
+                if (lane == src) { k1 = t1; k2 = t2; }
+                longs &= longs - 1;
+            }
+        }
+        return valid && c != 0 ? commit(i, k1, k2) : (valid ? commit(i, ~0ull, ~0ull) : false);
+    };
     if (mode != 1) {
         // Event-driven rounds (no second candidate, so a query's choice can only change when it loses its slot): the
         // first round steps every query, every later one only the queries the previous round pushed out -- the whole
@@ -1134,7 +1313,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
         int c_in = 5, c_out = 6, c_clr = 7, rounds = 0;
         unsigned short *w_in = S.wl[0], *w_out = S.wl[1];
         wl_next = w_out; wl_count = &S.vars[c_out];
-        for (int i = tid; i < nq; i += T) step(i);
+        for (int i0 = 0; i0 < nq; i0 += T) step_group(i0 + tid, i0 + tid < nq);
         __syncthreads();
         for (;; ++rounds) {
             { unsigned short *t_ = w_in; w_in = w_out; w_out = t_; }
@@ -1143,14 +1322,14 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
             if (nw == 0 || rounds > 65 * nq) break;
             if (tid == 0) S.vars[c_clr] = 0;
             wl_next = w_out; wl_count = &S.vars[c_out];
-            for (int k = tid; k < nw; k += T) step((int)w_in[k]);
+            for (int k0 = 0; k0 < nw; k0 += T) step_group(k0 + tid < nw ? (int)w_in[k0 + tid] : 0, k0 + tid < nw);
             __syncthreads();
         }
         wl_next = nullptr;
         bool unobs = false;
         for (int i = tid; i < nq; i += T) unobs |= !S.q_obs[i];
-        if (__any(unobs))
-            for (int i = tid; i < nq; i += T) if (!S.q_obs[i]) step(i);
+        if (__syncthreads_or(unobs))
+            for (int i0 = 0; i0 < nq; i0 += T) step_group(i0 + tid, i0 + tid < nq && !S.q_obs[i0 + tid]);
 #ifdef ORBHIP_DEVTOOLS
         if (tid == 0) { atomicAdd(&g_resolve_stats[0], 1u); atomicAdd(&g_resolve_stats[1], (unsigned)rounds + 1); atomicMax(&g_resolve_stats[2], (unsigned)rounds + 1); }
 #endif
@@ -1170,7 +1349,7 @@ __global__ __launch_bounds__(1024) void k_resolve_par(int mode, DevFrame F, cons
             __syncthreads();
             holder = own_cur; claim = own_nxt;
             bool ch = false;
-            for (int i = tid; i < nq; i += T) ch |= step(i);
+            for (int i0 = 0; i0 < nq; i0 += T) ch |= step_group(i0 + tid, i0 + tid < nq);
             if (ch) S.vars[0] = 1;
             __syncthreads();
             const int changed = S.vars[0];
@@ -2387,7 +2566,8 @@ static int launch_resolve_par(orbhip_matcher *m, int pairs, int mode, const DevF
 // CSR grid of the train frames + the cell-window search: candidates of every query
 static int launch_window_search(orbhip_matcher *m, int pairs, const DevFrame &D, int n_train_cap, const orbhip_query *d_q,
                                 const uint8_t *d_qdesc, int nq, unsigned long long *d_cand, int *d_cnt, int stride, int use_ur,
-                                const Batch &B, unsigned long long **d_ccand_out, const ProjLaunch *proj = nullptr)
+                                const Batch &B, unsigned long long **d_ccand_out, const uint8_t *d_taken, int max_dist,
+                                const ProjLaunch *proj = nullptr)
 {
     void *p;
     int rc;
@@ -2410,7 +2590,7 @@ static int launch_window_search(orbhip_matcher *m, int pairs, const DevFrame &D,
         hipLaunchKernelGGL(k_grid_build, dim3(pairs), dim3(256), 0, m->stream, D, d_start, d_rec, d_rdesc, d_rur, B);
     }
     hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4, pairs), dim3(256), 0, m->stream, D, d_start, d_rec, d_rdesc, d_rur, d_q,
-                       d_qdesc, nq, d_cand, d_ccand, d_cnt, stride, use_ur, B);
+                       d_qdesc, nq, d_cand, d_ccand, d_cnt, stride, use_ur, B, d_taken, max_dist);
     *d_ccand_out = d_ccand;
     return ORBHIP_OK;
 }
@@ -2483,7 +2663,8 @@ static int run_search(orbhip_matcher *m, int mode, const orbhip_frame_view *trai
     if ((rc = out_buffer(m, (size_t)(nout + 1) * sizeof(int), &h_out))) return rc;
     const Batch one = {nullptr, nullptr, 0, 0};
     unsigned long long *d_ccand;
-    if ((rc = launch_window_search(m, 1, D, train->n, d_q, d_qdesc, nqv, d_cand, d_cnt, stride, mode != 2 && use_ur, one, &d_ccand)))
+    if ((rc = launch_window_search(m, 1, D, train->n, d_q, d_qdesc, nqv, d_cand, d_cnt, stride, mode != 2 && use_ur, one, &d_ccand,
+                                   mode != 2 ? d_taken : nullptr, mode == 0 ? th_accept : 256)))
         return rc;
     if ((rc = ensure_resolve_attr(m))) return rc;
     if (mode == 2)   // SearchForInitialization: match stealing depends on the running minimum distance per slot
@@ -3119,7 +3300,7 @@ static int search_device(orbhip_matcher *m, int mode, int pairs, const void *d_k
     const Batch B = {(const int *)d_n, (const int *)d_nq, cap, qcap, t0, ts, qd0, qds};
     unsigned long long *d_ccand;
     if ((rc = launch_window_search(m, pairs, D, cap, (const orbhip_query *)d_q, (const uint8_t *)d_qdesc, qcap, d_cand, d_cnt, stride, 1,
-                                   B, &d_ccand, proj)))
+                                   B, &d_ccand, (const uint8_t *)d_taken, mode == 0 ? TH_HIGH : 256, proj)))
         return rc;
     if ((rc = launch_resolve_par(m, pairs, mode, D, (const orbhip_query *)d_q, qcap, cap, d_cand, d_ccand, d_cnt, stride,
                                  (const uint8_t *)d_taken, nnratio, check_ori, (int *)d_assign, (int *)d_nmatches, B, TH_HIGH, 0)))
@@ -3231,7 +3412,7 @@ int orbhip_search_for_initialization_device(orbhip_matcher *m, int pairs, const 
     D.min_x = min_x; D.min_y = min_y; D.inv_w = grid_inv_w; D.inv_h = grid_inv_h;
     const Batch B = {(const int *)d_n, d_nq, cap, cap, f2_first, f2_step, f1_first, f1_step};
     unsigned long long *d_ccand;
-    if ((rc = launch_window_search(m, pairs, D, cap, d_q, (const uint8_t *)d_desc, cap, d_cand, d_cnt, stride, 0, B, &d_ccand))) return rc;
+    if ((rc = launch_window_search(m, pairs, D, cap, d_q, (const uint8_t *)d_desc, cap, d_cand, d_cnt, stride, 0, B, &d_ccand, nullptr, 256))) return rc;
     launch_resolve_init(m, pairs, D, keys, d_q, cap, cap, d_cand, d_ccand, d_cnt, stride, nnratio, check_ori, (int *)d_matches12,
                         (int *)d_nmatches, B);
     hipLaunchKernelGGL(k_init_update_prev, dim3((cap + 255) / 256, pairs), dim3(256), 0, m->stream, keys, cap, f2_first, f2_step,

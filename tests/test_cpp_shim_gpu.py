@@ -11,17 +11,18 @@ from helpers import assert_kps_equal, frame_bounds, make_vocabulary, synth_frame
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "shim_smoke")
+def _build(tmp_path, name="shim_smoke"):
+    exe = str(tmp_path / name)
     libdir = os.path.join(ROOT, "orb_slam2_comment_amd")
-    subprocess.run(["g++", "-O2", "-std=c++11", "-I", os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "tests", "cpp", "shim_smoke.cpp"), "-o", exe, "-L", libdir, "-lorbhip",
+    subprocess.run(["g++", "-O2", "-std=c++11", "-Wall", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe, "-L", libdir, "-lorbhip",
                     "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     return exe
 
 
 def test_cpp_shim_compiles_against_the_header(tmp_path):
     _build(tmp_path)      # CPU-side: the mirror and the C ABI header are self-consistent C++11
+    _build(tmp_path, "track_smoke")
 
 
 @pytest.mark.gpu
@@ -59,3 +60,104 @@ def test_cpp_shim_matches_oracle(tmp_path, oracle):
     of = oracle.make_frame(okps, odesc, None, frame_bounds(img), sf, keep)
     on, om12 = oracle.search_by_bow(of, node, None, of, node, None, 50, 0.7, True)
     assert nm == on and np.array_equal(m12, om12)
+
+
+def _blob_write(path, records):
+    with open(path, "wb") as f:
+        for r in records:
+            b = r if isinstance(r, (bytes, bytearray)) else np.ascontiguousarray(r).tobytes()
+            f.write(np.int32(len(b)).tobytes())
+            f.write(b)
+
+
+def _blob_read(path):
+    buf, out, off = open(path, "rb").read(), [], 0
+    while off < len(buf):
+        nb = int(np.frombuffer(buf[off:off + 4], np.int32)[0])
+        out.append(buf[off + 4:off + 4 + nb])
+        off += 4 + nb
+    return out
+
+
+@pytest.mark.gpu
+def test_cpp_tracking_stereo_and_sim3_calls_match_oracle(tmp_path, oracle):
+    """The g++-built caller runs, through the C++ mirror only: the Tracking step (extract last + current frame ->
+    ProjectLastFrame -> SearchByProjection), the stereo constructor's ComputeStereoMatches and SearchBySim3; every result
+    is compared with the oracle on the same inputs."""
+    import orb_slam2_comment_amd as pkg
+    from orb_slam2_comment_amd import matcher as M
+    from helpers import synth_stereo
+    O = oracle
+    exe = _build(tmp_path, "track_smoke")
+    Wd, Hd, nf = 752, 480, 1000
+    fx = fy = 458.654; cx, cy, bf = 367.215, 248.375, 47.9
+    left, right = synth_stereo(5, Wd, Hd)
+    cur = synth_stereo(5, Wd, Hd, shift_xy=(4, 2))[0]
+    # the Python mirror on the same library gives the keypoints the map below is built from (the C++ run must reproduce them)
+    ext = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    kL, dL = ext(left)
+    kC, dC = ext(cur)
+    sf = ext.GetScaleFactors()
+    b = frame_bounds(left)
+    cam = M.make_camera(fx, fy, cx, cy, b, sf, mbf=bf, mb=bf / fx)
+    z = np.float32(9.0)
+    rng = np.random.default_rng(3)
+    Tlw = np.eye(4, dtype=np.float32)
+    Tcw = np.eye(4, dtype=np.float32)
+    Tcw[0, 3] = np.float32(4.0) * z / np.float32(fx); Tcw[1, 3] = np.float32(2.0) * z / np.float32(fy)
+    X = np.stack([(kL["x"] - np.float32(cx)) * z / np.float32(fx), (kL["y"] - np.float32(cy)) * z / np.float32(fy),
+                  np.full(len(kL), z, np.float32)], 1).astype(np.float32)
+    flags = np.where(rng.random(len(kL)) < 0.9, 3, np.where(rng.random(len(kL)) < 0.5, 1, 0)).astype(np.uint8)
+    th, mono = 15.0, 1
+    # Sim3 inputs as tests/test_projection_gpu.py builds them
+    T1w, T2w = Tlw, Tcw
+    S12 = np.eye(4, dtype=np.float32); S12[:3, 3] = -T2w[:3, 3]
+    S21 = np.eye(4, dtype=np.float32); S21[:3, 3] = T2w[:3, 3]
+    X2 = np.stack([(kC["x"] - np.float32(cx)) * z / np.float32(fx) - T2w[0, 3], (kC["y"] - np.float32(cy)) * z / np.float32(fy) - T2w[1, 3],
+                   np.full(len(kC), z, np.float32)], 1).astype(np.float32)
+    mx1 = (z * np.float32(1.2) ** kL["octave"].astype(np.float32)).astype(np.float32)
+    mx2 = (z * np.float32(1.2) ** kC["octave"].astype(np.float32)).astype(np.float32)
+    mn1, mn2 = (mx1 / np.float32(3.58)).astype(np.float32), (mx2 / np.float32(3.58)).astype(np.float32)
+    f1 = (rng.random(len(kL)) < 0.9).astype(np.uint8)
+    f2 = (rng.random(len(kC)) < 0.9).astype(np.uint8)
+    th_sim3 = 7.5
+    rec = [np.array([Hd, Wd, nf], np.int32), left, right, cur, bytes(cam), Tcw[:3].copy(), Tlw[:3].copy(), X, flags,
+           np.array([th], np.float32).tobytes() + np.array([mono], np.int32).tobytes(),
+           T1w[:3].copy(), T2w[:3].copy(), S21[:3].copy(), S12[:3].copy(), X, mx1, mn1, f1, X2, mx2, mn2, f2,
+           np.array([th_sim3], np.float32), np.array([bf, bf / fx], np.float32)]
+    blob_in, blob_out = str(tmp_path / "in.blob"), str(tmp_path / "out.blob")
+    _blob_write(blob_in, rec)
+    r = subprocess.run([exe, blob_in, blob_out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = _blob_read(blob_out)
+    assert len(out) == 15
+    kp = lambda bts: np.frombuffer(bts, pkg.KP_DTYPE)
+    dd = lambda bts: np.frombuffer(bts, np.uint8).reshape(-1, 32)
+    oL, oR, oC = (O.OracleExtractor(nf, 1.2, 8, 20, 7) for _ in range(3))
+    okL, odL = oL.extract(left); okR, odR = oR.extract(right); okC, odC = oC.extract(cur)
+    for got_k, got_d, want_k, want_d in ((out[0], out[1], okL, odL), (out[2], out[3], okR, odR), (out[4], out[5], okC, odC)):
+        assert_kps_equal(kp(got_k), want_k)
+        assert np.array_equal(dd(got_d), want_d)
+    assert_kps_equal(kp(out[0]), kL)
+    # Tracking step
+    q = np.frombuffer(out[6], pkg.QUERY_DTYPE)
+    oq = O.project_last_frame(cam, Tcw, Tlw, X, flags, okL, th, bool(mono))
+    assert q.tobytes() == np.ascontiguousarray(oq, pkg.QUERY_DTYPE).tobytes()
+    keep = []
+    ovC = O.make_frame(okC, odC, None, b, sf, keep)
+    on, oassign = O.search_by_projection_frame(ovC, oq, odL, None, True)
+    assert np.array_equal(np.frombuffer(out[7], np.int32), oassign) and int(np.frombuffer(out[8], np.int32)[0]) == on and on > 200
+    # stereo
+    lv_l = [np.ascontiguousarray(oL.level_padded(l))[19:-19, 19:-19] for l in range(8)]
+    lv_r = [np.ascontiguousarray(oR.level_padded(l))[19:-19, 19:-19] for l in range(8)]
+    t = oL.tables()
+    osn, our, odp = O.compute_stereo_matches(okL, odL, okR, odR, lv_l, lv_r, t["scale"], t["inv_scale"], float(np.float32(bf)),
+                                             float(np.float32(bf / fx)))
+    assert int(np.frombuffer(out[11], np.int32)[0]) == osn and osn > 100
+    assert np.array_equal(np.frombuffer(out[9], np.float32), our) and np.array_equal(np.frombuffer(out[10], np.float32), odp)
+    # SearchBySim3
+    ov1 = O.make_frame(okL, odL, None, b, sf, keep)
+    onn, om12 = O.search_by_sim3(ov1, ovC, cam, T1w, T2w, S21, S12, (X, mx1, mn1, f1, odL), (X2, mx2, mn2, f2, odC), th_sim3)
+    assert np.array_equal(np.frombuffer(out[12], np.int32), om12) and int(np.frombuffer(out[13], np.int32)[0]) == onn and onn > 200
+    # the lazily produced mvImagePyramid[0] of the current frame
+    assert np.array_equal(np.frombuffer(out[14], np.uint8).reshape(Hd, Wd), cur)
