@@ -98,6 +98,17 @@ int orbhip_extractor_set_blur_kernel(orbhip_extractor *e, const int32_t w[7]);
  * Default 0: every extraction materialises it, as the reference does. */
 int orbhip_extractor_set_lazy_level0(orbhip_extractor *e, int on);
 
+/* Several extractor handles on several streams (the reference runs two on two threads for a stereo sensor,
+ * src/Frame.cc:78-81; a batch front-end runs a few pipelines side by side): which of their kernels meet on the GPU decides
+ * how well they share it, and free-running streams settle into one of several phase patterns.  A stage gate pins the
+ * pattern: before launching stage `stage` (0 pyramid, 1 FAST, 2 octree, 3 descriptors) the handle's stream waits for
+ * `wait_event` (hipEvent_t, null = no wait), after it `record_event` is recorded (null = none).  Chaining the FAST stages
+ * of N handles in a ring (handle h waits for the event handle h-1 records) keeps the N VALU-bound FAST kernels from
+ * running beside each other.  Events are owned by the caller and must outlive their use; results never depend on gates.
+ * ORBHIP_GATE_KEEP for either event leaves that side of the stage's gate as it is. */
+#define ORBHIP_GATE_KEEP ((void *)(intptr_t)-1)
+int orbhip_extractor_set_stage_gate(orbhip_extractor *e, int stage, void *wait_event, void *record_event);
+
 /* ORBextractor::operator()(image, mask(ignored), keypoints, descriptors)
  * (src/ORBextractor.cc:1043-1105).  image: rows x cols uint8, row stride `stride` bytes (host).
  * kps[cap], desc[cap*32] host buffers; *n = number of keypoints (0 is success). */

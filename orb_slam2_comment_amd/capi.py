@@ -55,6 +55,7 @@ SYMBOLS = [
     ("orbhip_extractor_capacity", _i, [_vp, _i, _i, _pi]),
     ("orbhip_extractor_set_blur_kernel", _i, [_vp, _vp]),
     ("orbhip_extractor_set_lazy_level0", _i, [_vp, _i]),
+    ("orbhip_extractor_set_stage_gate", _i, [_vp, _i, _vp, _vp]),
     ("orbhip_extract", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _pi]),
     ("orbhip_extract_batch", _i, [_vp, _vp, _i, _i, _i, _i, _sz, _vp, _vp, _i, _vp]),
     ("orbhip_extract_batch_device", _i, [_vp, _vp, _i, _i, _i, _i, _sz, _vp, _vp, _i, _vp, _vp]),

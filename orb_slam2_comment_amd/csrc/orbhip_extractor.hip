@@ -1270,9 +1270,11 @@ constexpr int kWinWords = kWinRows * kWinDw + 7;   // + the dwords the last colu
 constexpr int kHPairs = 22, kHGroups = 10;    // row-pass results: 22 pair-rows x 10 groups of 4 columns (uint4 each)
 
 #ifndef ORBHIP_DESC_WAVES
-#define ORBHIP_DESC_WAVES 5   // resident waves per SIMD (the allocation is padded to 81 VGPRs; the kernel needs 66).  One pipeline alone is fastest at 6-7
-                              // (175 vs 188 us per 172 frames); three concurrent pipelines at 5: 244-245 k frames/s in both rounds of
-                              // tools/ab_build.sh against 235-245 k (6) and 236 k (7) -- fewer descriptor waves leave the other pipelines room
+#define ORBHIP_DESC_WAVES 7   // resident waves per SIMD the register allocation is held to (the kernel needs 66 VGPRs; LDS allows 7
+                              // workgroups per CU).  tools/ab_build.sh, 512 frames as three pipelines whose pyramid stages are
+                              // chained by a stage gate (bench.py --gates 0): 5: 254 k, 6: 259 k, 7: 260 k frames/s.  Free-running
+                              // pipelines (no gate) preferred 5 (244-248 k against 235-246 k): fewer descriptor waves left the
+                              // other pipelines' kernels room
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBHIP_DESC_WAVES, ORBHIP_DESC_WAVES))) void k_describe_fused(const uint8_t *__restrict__ pyr, PyrGeom G,
                                                         const uint32_t *__restrict__ sel_kp,
@@ -1919,6 +1921,9 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     if (!(sm & 1))   // k_pyr_base clears the status words itself
         hipLaunchKernelGGL(k_zero_status, dim3((batch + 255) / 256), dim3(256), 0, s, status, batch);
     if (prof) (void)hipEventRecord(ev[0], s);
+#define ORBHIP_GATE_IN(st) do { if (e->gate_wait[st]) (void)hipStreamWaitEvent(s, e->gate_wait[st], 0); } while (0)
+#define ORBHIP_GATE_OUT(st) do { if (e->gate_rec[st]) (void)hipEventRecord(e->gate_rec[st], s); } while (0)
+    ORBHIP_GATE_IN(0);
     if (sm & 1) {
         // level 0 and, when its taps allow, level 1 in one launch
         const bool l1_rows = G.nlevels > 1 && e->ptab_rows[1];
@@ -1939,7 +1944,9 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
             hipLaunchKernelGGL(k_pyr_resize, dim3((nl + 255) / 256, batch), dim3(256), 0, s, b_pyr, G, l, RS);
         }
     }
+    ORBHIP_GATE_OUT(0);
     if (prof) (void)hipEventRecord(ev[1], s);
+    ORBHIP_GATE_IN(1);
     if (G.ncells_total > 0 && (sm & 2)) {
         const dim3 grid(G.ncells_total, batch);
         const size_t lb = (size_t)e->fast_lds_bytes;
@@ -1965,7 +1972,9 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         }
 #undef ORBHIP_FAST2
     }
+    ORBHIP_GATE_OUT(1);
     if (prof) (void)hipEventRecord(ev[2], s);
+    ORBHIP_GATE_IN(2);
     if (sm & 4) {
         const int ot = e->octree_threads;
 #define ORBHIP_OCT(MAXNv, Tv) hipLaunchKernelGGL((k_octree<MAXNv, Tv>), dim3(G.nlevels, batch), dim3(Tv), 0, s, G, b_cell_cnt, b_cell_kp, \
@@ -1977,7 +1986,9 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
         }
 #undef ORBHIP_OCT
     }
+    ORBHIP_GATE_OUT(2);
     if (prof) (void)hipEventRecord(ev[3], s);
+    ORBHIP_GATE_IN(3);
     if (sm & 16) {
         // IC_Angle + the 7x7 blur of the keypoint's patch + rBRIEF in one kernel: no blurred plane exists unless
         // orbhip_blurred_level_download asks for one
@@ -1987,6 +1998,9 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
                            reinterpret_cast<const uint32_t *>(e->d_desc_tab + 768), lazy ? d_images : (const uint8_t *)nullptr, stride,
                            frame_stride);
     }
+    ORBHIP_GATE_OUT(3);
+#undef ORBHIP_GATE_IN
+#undef ORBHIP_GATE_OUT
     if (prof) { (void)hipEventRecord(ev[4], s); e->prof_calls++; }
     e->last_batch = frame0 + batch;
     ORBHIP_HIP_CHECK(hipGetLastError());
@@ -2176,6 +2190,17 @@ int orbhip_extractor_set_lazy_level0(orbhip_extractor *e, int on)
     ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
     drop_graph(e);   // which kernels run, and their arguments, depend on it
     e->lazy_l0 = on != 0;
+    return ORBHIP_OK;
+}
+
+int orbhip_extractor_set_stage_gate(orbhip_extractor *e, int stage, void *wait_event, void *record_event)
+{
+    if (!e || stage < 0 || stage > 3) return ORBHIP_E_ARG;
+    ORBHIP_HIP_CHECK(hipSetDevice(e->device));
+    ORBHIP_HIP_CHECK(hipStreamSynchronize(e->stream));
+    drop_graph(e);
+    if (wait_event != ORBHIP_GATE_KEEP) e->gate_wait[stage] = (hipEvent_t)wait_event;
+    if (record_event != ORBHIP_GATE_KEEP) e->gate_rec[stage] = (hipEvent_t)record_event;
     return ORBHIP_OK;
 }
 

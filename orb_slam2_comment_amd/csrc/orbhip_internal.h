@@ -97,6 +97,8 @@ struct orbhip_extractor {
     int cells_stride = 0;           // image row stride the level-0 entries of d_cells2 are built for (0: the padded plane)
     const uint8_t *src_images = nullptr; int src_stride = 0; size_t src_frame_stride = 0;   // image buffer of the last extraction
     hipEvent_t ev_l0 = nullptr;
+    // stage gates (orbhip_extractor_set_stage_gate): events other pipelines' handles record / wait for
+    hipEvent_t gate_wait[4] = {nullptr, nullptr, nullptr, nullptr}, gate_rec[4] = {nullptr, nullptr, nullptr, nullptr};
     float4 *d_patternf = nullptr;   // rBRIEF pattern as floats: (x0, y0, x1, y1) per test
     uint8_t *d_pyrtab = nullptr;    // row / column tables of the pyramid kernels
     orbhip::PyrLevelTab ptab[ORBHIP_MAX_LEVELS];

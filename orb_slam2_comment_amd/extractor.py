@@ -86,6 +86,17 @@ class ORBextractor:
         it); the first accessor that needs it builds it from the image buffer of the last extraction."""
         check(self._lib.orbhip_extractor_set_lazy_level0(self._h, int(on)), "orbhip_extractor_set_lazy_level0")
 
+    def set_stage_gate(self, stage, wait_event=0, record_event=0):
+        """Before launching stage 0 pyramid / 1 FAST / 2 octree / 3 descriptors wait for `wait_event`, after it record
+        `record_event` (hipEvent_t handles as int, 0 = none): pins how several pipelines' kernels meet on the GPU."""
+        check(self._lib.orbhip_extractor_set_stage_gate(self._h, stage, wait_event, record_event), "orbhip_extractor_set_stage_gate")
+
+    def set_stage_gate_wait(self, stage, wait_event):
+        check(self._lib.orbhip_extractor_set_stage_gate(self._h, stage, wait_event, C.c_void_p(-1)), "orbhip_extractor_set_stage_gate")
+
+    def set_stage_gate_record(self, stage, record_event):
+        check(self._lib.orbhip_extractor_set_stage_gate(self._h, stage, C.c_void_p(-1), record_event), "orbhip_extractor_set_stage_gate")
+
     # -- operator() ---------------------------------------------------------
     def __call__(self, image, mask=None):
         """image: uint8 [rows, cols] (CV_8UC1).  Returns (keypoints[KP_DTYPE], descriptors[n,32])."""

@@ -547,3 +547,44 @@ def test_lazy_level0_device_entry_with_strides_and_stereo(mods):
         res.append(pkg.ORBmatcher().ComputeStereoMatches(eL, eR, kl, dl, kr, dr, 386.1448, 386.1448 / 718.856))
     assert res[0][0] == res[1][0] and res[0][0] > 50
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_stage_gates_do_not_change_results(mods):
+    """orbhip_extractor_set_stage_gate: three handles on three streams with their pyramid stages chained in a ring and
+    their descriptor stages gated on another handle's FAST stage -- scheduling only, results identical to an ungated run."""
+    import torch
+    pkg, O = mods
+    imgs = [synth_frame(90 + s, 640, 360) for s in range(6)]
+    d_img = torch.from_numpy(np.stack(imgs)).cuda()
+    exts = [pkg.ORBextractor(500, 1.2, 8, 20, 7) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    evs = [[torch.cuda.Event() for _ in range(3)] for _ in range(2)]
+    for h in range(3):
+        exts[h].set_stream(streams[h].cuda_stream)
+        for ring in evs:
+            ring[h].record(streams[h])
+    torch.cuda.synchronize()
+    for h in range(3):
+        exts[h].set_stage_gate(0, evs[0][(h - 1) % 3].cuda_event, evs[0][h].cuda_event)      # pyramid ring
+        exts[h].set_stage_gate_record(1, evs[1][h].cuda_event)                                 # FAST of h ...
+        exts[h].set_stage_gate_wait(3, evs[1][(h + 1) % 3].cuda_event)                         # ... releases descriptors of h - 1
+    cap = exts[0].capacity(360, 640)
+    k = torch.zeros((6, cap, 7), dtype=torch.int32, device="cuda"); d = torch.zeros((6, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(6, dtype=torch.int32, device="cuda"); st = torch.zeros(6, dtype=torch.int32, device="cuda")
+    for rep in range(3):
+        for h in range(3):
+            sl = slice(2 * h, 2 * h + 2)
+            exts[h].extract_batch_device(d_img[sl].data_ptr(), 2, 360, 640, k[sl].data_ptr(), d[sl].data_ptr(), cap, n[sl].data_ptr(),
+                                         st[sl].data_ptr())
+    torch.cuda.synchronize()
+    assert int(st.abs().sum().item()) == 0
+    nn = n.cpu().numpy()
+    kk = k.cpu().numpy().view(np.uint8).reshape(6, cap, 28).view(pkg.capi.KP_DTYPE).reshape(6, cap)
+    dd = d.cpu().numpy()
+    ora = O.OracleExtractor(500, 1.2, 8, 20, 7)
+    for b in range(6):
+        okps, odesc = ora.extract(imgs[b])
+        assert_kps_equal(kk[b, :nn[b]], okps, "frame %d" % b)
+        assert np.array_equal(dd[b, :nn[b]], odesc)
+    for e in exts:
+        e.set_stage_gate(0, 0, 0); e.set_stage_gate(1, 0, 0); e.set_stage_gate(3, 0, 0); e.set_stream(0)

@@ -34,17 +34,32 @@ out = {
                 "hbm_bytes_per_frame": round((hbm(find("k_pyr_base")) + npyr_rows * hbm(find("k_pyr_rows"))) / frames)},
     "octree": {"kernel": ko, "hbm_bytes_per_frame": round(hbm(ko) / frames)},
 }
-# VALU issue load of every stage ("report VALU utilisation alongside"): one VALU instruction occupies its
-# SIMD for 4 cycles (wave64 on a 16-lane SIMD); 256 CUs x 4 SIMDs, 2.4 GHz
-for stage, key in (("fast", kf), ("describe", kd), ("octree", ko)):
+# VALU issue load of every stage ("report VALU utilisation alongside"): PMC SQ_INSTS_VALU x the mean issue
+# cost of the kernel's instruction mix (tools/valu_mix.py: static mix x the per-class costs measured by tools/micro on
+# MI355X -- 1.06 ns for the fast class, 1.78 ns for the rest, 2.26 ns for f64 arithmetic, per wave-instruction per SIMD)
+# / 1024 SIMDs.  The SALU stream (1.74 ns per instruction per SIMD) issues beside it and is reported for k_fast_cells.
+import os
+import subprocess
+mix = json.loads(subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "valu_mix.py")],
+                                check=True, capture_output=True, text=True).stdout)
+cost = {k: v["mean_issue_ns"] for k, v in mix["kernels"].items()}
+model = mix["_model"]
+for stage, key, mk in (("fast", kf, "k_fast_cells<11>"), ("describe", kd, "k_describe_fused"), ("octree", ko, "k_octree")):
     v = d[key]
     if "SQ_INSTS_VALU" in v:
         out[stage]["valu_insts_per_frame"] = round(v["SQ_INSTS_VALU"] / frames)
-        out[stage]["valu_issue_us_per_frame"] = round(v["SQ_INSTS_VALU"] / frames * 4 / 1024 / 2.4e3, 4)
+        out[stage]["valu_issue_ns_per_inst"] = cost[mk]
+        out[stage]["valu_issue_us_per_frame"] = round(v["SQ_INSTS_VALU"] / frames * cost[mk] * 1e-3 / 1024, 4)
+        out[stage]["valu_issue_model"] = model
+        if "SQ_INSTS_SALU" in v:
+            out[stage]["salu_insts_per_frame"] = round(v["SQ_INSTS_SALU"] / frames)
+            out[stage]["salu_issue_us_per_frame"] = round(v["SQ_INSTS_SALU"] / frames * 1.74e-3 / 1024, 4)
 v = [d[find("k_pyr_base")], d[find("k_pyr_rows")]]
 if all("SQ_INSTS_VALU" in x for x in v):
     n = v[0]["SQ_INSTS_VALU"] + npyr_rows * v[1]["SQ_INSTS_VALU"]
     out["pyramid"]["valu_insts_per_frame"] = round(n / frames)
-    out["pyramid"]["valu_issue_us_per_frame"] = round(n / frames * 4 / 1024 / 2.4e3, 4)
+    out["pyramid"]["valu_issue_ns_per_inst"] = cost["k_pyr_rows"]
+    out["pyramid"]["valu_issue_us_per_frame"] = round(n / frames * cost["k_pyr_rows"] * 1e-3 / 1024, 4)
+    out["pyramid"]["valu_issue_model"] = model
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -22,6 +22,9 @@ echo "bench done"
 python3 tools/bench_host_path.py > $OUT/host_path.json 2> $OUT/host_path.err
 python3 tools/bench_host_path.py --pinned > $OUT/host_path_pinned.json 2>> $OUT/host_path.err
 python3 tools/bench_matchers.py > $OUT/matcher_latency.json 2> $OUT/matcher_latency.err
+python3 tools/bench_track_th.py > $OUT/track_th.json 2> $OUT/track_th.err
+timeout -k 5 100 ./tools/micro/valu_rate2 > $OUT/issue_rates.txt 2>&1 || true
+timeout -k 5 100 ./tools/micro/valu_rate3 >> $OUT/issue_rates.txt 2>&1 || true
 rm -rf $OUT/stats2 $OUT/stats1
 cat $OUT/bench_final.json
 cat $OUT/host_path.json $OUT/host_path_pinned.json
