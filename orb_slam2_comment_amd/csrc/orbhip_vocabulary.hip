@@ -261,16 +261,19 @@ int upload_tree(const HostTree &T, int device, orbhip_vocabulary **out)
     }
     v->stream = v->own_stream;
     uint8_t *d = (uint8_t *)v->d_tree;
-    bool ok = hipMemcpy(d, off.data(), (N + 1) * 4, hipMemcpyHostToDevice) == hipSuccess;
+    // one-off upload of the tree: stream-ordered copies on the handle's own stream (the host vectors outlive the wait below)
+    hipStream_t us = v->own_stream;
+    bool ok = hipMemcpyAsync(d, off.data(), (N + 1) * 4, hipMemcpyHostToDevice, us) == hipSuccess;
     v->dev.child_off = (const uint32_t *)d; d += b_off;
-    ok = ok && hipMemcpy(d, cid.data(), cid.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d, cid.data(), cid.size() * 4, hipMemcpyHostToDevice, us) == hipSuccess;
     v->dev.child_id = (const uint32_t *)d; d += b_cid;
-    ok = ok && hipMemcpy(d, cdesc.data(), cdesc.size(), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d, cdesc.data(), cdesc.size(), hipMemcpyHostToDevice, us) == hipSuccess;
     v->dev.child_desc = d; d += b_desc;
-    ok = ok && hipMemcpy(d, wid.data(), N * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d, wid.data(), N * 4, hipMemcpyHostToDevice, us) == hipSuccess;
     v->dev.word_id = (const uint32_t *)d; d += b_wid;
-    ok = ok && hipMemcpy(d, T.weight.data(), N * 8, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d, T.weight.data(), N * 8, hipMemcpyHostToDevice, us) == hipSuccess;
     v->dev.weight = (const double *)d;
+    ok = ok && hipStreamSynchronize(us) == hipSuccess;
     v->dev.L = T.L; v->dev.scoring = T.scoring; v->dev.weighting = T.weighting; v->dev.n_words = n_words;
     if (!ok) {
         set_error("vocabulary: upload failed");
