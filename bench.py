@@ -724,9 +724,9 @@ def secondary_legs(args, torch, dev, local_rank, head):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 
     def stereo_extract_and_match():
+        sR.wait_stream(sL)                     # the right extraction of step k+1 must not overtake the stereo search of step k
         eL.extract_batch_device(d_left.data_ptr(), Bs, H, W, so["kL"].data_ptr(), so["dL"].data_ptr(), cap, so["nL"].data_ptr(),
                                 so["sL"].data_ptr())
-        sR.wait_stream(sL)                     # the right extraction of step k+1 must not overtake the stereo search of step k
         eR.extract_batch_device(d_right.data_ptr(), Bs, H, W, so["kR"].data_ptr(), so["dR"].data_ptr(), cap, so["nR"].data_ptr(),
                                 so["sR"].data_ptr())
         sL.wait_stream(sR)

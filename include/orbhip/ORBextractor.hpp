@@ -88,6 +88,13 @@ public:
     // mvImagePyramid[0] on demand: a monocular Tracking thread never reads it (only Frame::ComputeStereoMatches does)
     void SetLazyLevel0(bool on) { check(orbhip_extractor_set_lazy_level0(h_, on ? 1 : 0), "orbhip_extractor_set_lazy_level0"); }
 
+    // several extractors on several streams: chain a stage (0 pyramid, 1 FAST, 2 octree, 3 descriptors) behind another
+    // handle's through hipEvent_t handles (scheduling only, see orbhip_extractor_set_stage_gate)
+    void SetStageGate(int stage, void *waitEvent, void *recordEvent)
+    {
+        check(orbhip_extractor_set_stage_gate(h_, stage, waitEvent, recordEvent), "orbhip_extractor_set_stage_gate");
+    }
+
     int GetLevels() { return nlevels_; }
     float GetScaleFactor() { return tab(0).size() > 1 ? tab(0)[1] : 1.f; }
     std::vector<float> GetScaleFactors() { return tab(0); }
