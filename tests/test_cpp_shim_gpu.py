@@ -23,6 +23,7 @@ def _build(tmp_path, name="shim_smoke"):
 def test_cpp_shim_compiles_against_the_header(tmp_path):
     _build(tmp_path)      # CPU-side: the mirror and the C ABI header are self-consistent C++11
     _build(tmp_path, "track_smoke")
+    _build(tmp_path, "matcher_smoke")
 
 
 @pytest.mark.gpu
@@ -161,3 +162,107 @@ def test_cpp_tracking_stereo_and_sim3_calls_match_oracle(tmp_path, oracle):
     assert np.array_equal(np.frombuffer(out[12], np.int32), om12) and int(np.frombuffer(out[13], np.int32)[0]) == onn and onn > 200
     # the lazily produced mvImagePyramid[0] of the current frame
     assert np.array_equal(np.frombuffer(out[14], np.uint8).reshape(Hd, Wd), cur)
+
+
+@pytest.mark.gpu
+def test_cpp_remaining_matcher_methods_match_oracle(tmp_path, oracle):
+    """tests/cpp/matcher_smoke.cpp: SearchForInitialization, FrustumQueries + SearchByProjection(F, vpMapPoints), the
+    key-frame and Sim3 projection searches, Fuse in both forms and SearchForTriangulation, all through the C++ mirror of a
+    g++-built program, against the oracle on the same inputs.  With shim_smoke (SearchByBoW) and track_smoke
+    (SearchByProjection(Frame, Frame), SearchBySim3, ComputeStereoMatches) every method of include/ORBmatcher.h:44-83 is
+    called from C++."""
+    import orb_slam2_comment_amd as pkg
+    from orb_slam2_comment_amd import matcher as M
+    from test_projection_gpu import _pose, _synthetic_map_for
+    from test_matcher_gpu import _pseudo_nodes
+    O = oracle
+    exe = _build(tmp_path, "matcher_smoke")
+    rng = np.random.default_rng(77)
+    Wd, Hd = 1241, 376
+    fx = fy = 718.856; cx, cy, bf = 607.1928, 185.2157, 386.1448
+    ext = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    img1, img2 = synth_frame(15), synth_frame(15, shift_xy=(4, 1))
+    k1, d1 = ext(img1)
+    k2, d2 = ext(img2)
+    sf = ext.GetScaleFactors()
+    sigma2 = ext.GetScaleSigmaSquares()
+    b = frame_bounds(img1)
+    cam = M.make_camera(fx, fy, cx, cy, b, sf, mbf=bf, mb=bf / fx)
+    ur1 = np.where(rng.random(len(k1)) < 0.5, k1["x"] - rng.uniform(2, 60, len(k1)), -1).astype(np.float32)
+    ur2 = np.where(rng.random(len(k2)) < 0.5, k2["x"] - rng.uniform(2, 60, len(k2)), -1).astype(np.float32)
+    keep = []
+    o1, o2 = O.make_frame(k1, d1, None, b, sf, keep), O.make_frame(k2, d2, None, b, sf, keep)
+    o1s, o2s = O.make_frame(k1, d1, ur1, b, sf, keep), O.make_frame(k2, d2, ur2, b, sf, keep)
+    # SearchForInitialization
+    prev = (np.stack([k1["x"], k1["y"]], 1) + rng.normal(0, 1.5, (len(k1), 2))).astype(np.float32)
+    window = 100
+    # local map seen from pose Tcw: points behind the keypoints of frame 2
+    Tcw = _pose(rng)
+    X, nrm, max_d, min_d = _synthetic_map_for(k2, cam, Tcw, rng)
+    flags = ((rng.random(len(k2)) < 0.9).astype(np.uint8) * pkg.capi.POINT_PRESENT) | \
+            ((rng.random(len(k2)) < 0.8).astype(np.uint8) * pkg.capi.POINT_OBSERVED)
+    th_pts = 3.0
+    pdesc = d2 ^ ((rng.random(d2.shape) < 0.03).astype(np.uint8) * rng.integers(1, 256, d2.shape, dtype=np.uint8))
+    taken = (rng.random(len(k2)) < 0.1).astype(np.uint8)
+    # key-frame / Sim3 projection searches: queries from frame 1's keypoints
+    nq = len(k1)
+    q = np.zeros(nq, pkg.QUERY_DTYPE)
+    q["valid"] = rng.random(nq) < 0.9
+    q["u"] = k1["x"] + 4 + rng.normal(0, 1.5, nq).astype(np.float32)
+    q["v"] = k1["y"] + 1 + rng.normal(0, 1.5, nq).astype(np.float32)
+    pred = np.clip(k1["octave"] + rng.integers(-1, 2, nq), 0, 7)
+    q["radius"] = np.float32(10) * sf[pred]
+    q["min_level"], q["max_level"] = pred - 1, pred + 1
+    q["angle"] = k1["angle"]
+    q3 = q.copy()
+    q3["max_level"] = pred
+    orb_dist = 64
+    # Fuse: the same map against frame 2 as a key frame with stereo coordinates
+    Tf = _pose(rng)
+    Xf, nf_, mxf, mnf = _synthetic_map_for(k2, cam, Tf, rng)
+    ff = (rng.random(len(k2)) < 0.9).astype(np.uint8)
+    inv_sigma2 = (1.0 / (sf * sf)).astype(np.float32)
+    fuse_th = np.array([3.0, 4.0], np.float32)
+    # SearchForTriangulation
+    node1, node2 = _pseudo_nodes(d1, 100, rng), _pseudo_nodes(d2, 100, rng)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    epi = (Wd / 2.0, Hd / 2.0)
+    misc = np.concatenate([F12.reshape(-1), np.array(epi, np.float32), sigma2.astype(np.float32)]).astype(np.float32)
+    rec = [k1, d1, k2, d2, sf, np.array(b, np.float32), bytes(cam), ur1, ur2, prev, np.array([window], np.int32),
+           Tcw[:3].copy(), X, nrm, max_d, min_d, flags, np.array([th_pts], np.float32), pdesc, taken,
+           q, d1, taken, q3, np.array([orb_dist], np.int32),
+           Tf[:3].copy(), Xf, nf_, mxf, mnf, ff, pdesc, fuse_th, inv_sigma2,
+           node1.astype(np.uint32), node2.astype(np.uint32), misc]
+    blob_in, blob_out = str(tmp_path / "m_in.blob"), str(tmp_path / "m_out.blob")
+    _blob_write(blob_in, rec)
+    r = subprocess.run([exe, blob_in, blob_out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = _blob_read(blob_out)
+    assert len(out) == 17
+    i32 = lambda bts: np.frombuffer(bts, np.int32)
+    # SearchForInitialization
+    on, om12, opm = O.search_for_initialization(o1, o2, prev, window, 0.9, True)
+    assert np.array_equal(i32(out[0]), om12) and np.array_equal(np.frombuffer(out[1], np.float32).reshape(-1, 2), opm)
+    assert int(i32(out[2])[0]) == on and on > 50
+    # FrustumQueries + SearchByProjection(F, vpMapPoints)
+    oq, ovc = O.frustum_queries(cam, Tcw, X, nrm, max_d, min_d, flags, 0.5, th_pts)
+    assert out[3] == np.ascontiguousarray(oq, pkg.QUERY_DTYPE).tobytes()
+    assert np.array_equal(np.frombuffer(out[4], np.float32).view(np.int32), ovc.view(np.int32))
+    on, oa = O.search_by_projection_points(o2, oq, pdesc, taken, 0.8)
+    assert np.array_equal(i32(out[5]), oa) and int(i32(out[6])[0]) == on and on > 100
+    # key-frame and Sim3 projection searches
+    on, oa = O.search_by_projection_block(o2, q, d1, taken, orb_dist, True)
+    assert np.array_equal(i32(out[7]), oa) and int(i32(out[8])[0]) == on and on > 50
+    on, oa = O.search_by_projection_block(o2, q3, d1, taken, 50, False)
+    assert np.array_equal(i32(out[9]), oa) and int(i32(out[10])[0]) == on and on > 50
+    # Fuse, both forms
+    for form in (0, 1):
+        oqf = O.keyframe_queries(cam, 0, bool(form), Tf, None, Xf, nf_, mxf, mnf, ff, float(fuse_th[form]))
+        obi, obd = O.search_best_in_window(o2s, oqf, pdesc, inv_sigma2)
+        assert np.array_equal(i32(out[11 + 2 * form]), obi) and np.array_equal(i32(out[12 + 2 * form]), obd)
+        assert (obd <= 50).sum() > 100
+    # SearchForTriangulation
+    on, om12 = O.search_for_triangulation(o1s, node1, None, o2s, node2, None, F12, epi[0], epi[1], sigma2, False, True)
+    pairs = i32(out[15]).reshape(-1, 2)
+    want = np.stack([np.nonzero(om12 >= 0)[0], om12[om12 >= 0]], 1)
+    assert np.array_equal(pairs, want) and int(i32(out[16])[0]) == on and on > 20
