@@ -2382,7 +2382,9 @@ int orbhip_extract_batch(orbhip_extractor *e, const uint8_t *images, int batch, 
     };
     // Every pointer and by-value argument of the sequence is fixed for a (geometry, batch, cap, buffers) combination:
     // capture it once, replay it with one launch.  Anything that would change an argument drops the graph.
-    if (!e->profiling) {
+    bool gated = false;   // stage gates wait for / record other streams' events: plain launches, no capture
+    for (int st = 0; st < 4; ++st) gated = gated || e->gate_wait[st] || e->gate_rec[st];
+    if (!e->profiling && !gated) {
         if (!e->graph_exec || e->graph_batch != batch || e->graph_cap != cap) {
             drop_graph(e);
             hipGraph_t graph = nullptr;

@@ -586,5 +586,11 @@ def test_stage_gates_do_not_change_results(mods):
         okps, odesc = ora.extract(imgs[b])
         assert_kps_equal(kk[b, :nn[b]], okps, "frame %d" % b)
         assert np.array_equal(dd[b, :nn[b]], odesc)
+    # the host entry with gates set (single frame: normally a hipGraph replay) takes plain launches instead
+    torch.cuda.synchronize()
+    kh, dh = exts[0](imgs[0])
+    okps, odesc = ora.extract(imgs[0])
+    assert_kps_equal(kh, okps)
+    assert np.array_equal(dh, odesc)
     for e in exts:
         e.set_stage_gate(0, 0, 0); e.set_stage_gate(1, 0, 0); e.set_stage_gate(3, 0, 0); e.set_stream(0)

@@ -43,6 +43,9 @@ def main():
         except Exception as e:      # geometry the library refuses (level too small): both sides must refuse alike
             print(desc, "-> constructor/geometry refused:", str(e)[:80])
             continue
+        lazy = bool(rng.random() < 0.5)              # mvImagePyramid[0] on demand: the accessors below must still see level 0
+        ext.set_lazy_level0(lazy)
+        desc += " lazy0" if lazy else ""
         img0, img1 = synth_frame(seed, W, H), synth_frame(seed, W, H, shift_xy=(sx, sy))
         try:
             k0, d0 = ext(img0)
@@ -57,6 +60,8 @@ def main():
         ok1, od1 = ora.extract(img1)
         assert_kps_equal(k1, ok1, desc + " (second frame)")
         assert np.array_equal(d1, od1), desc
+        if case % 4 == 1:
+            assert_stagewise_equal(ext, ora, nlev, desc + " (second frame, replayed graph)")
         if len(k0) < 8 or len(k1) < 8:
             print(desc, "-> %d / %d keypoints, matching skipped" % (len(k0), len(k1)))
             continue
@@ -72,7 +77,7 @@ def main():
         q["valid"] = rng.random(nq) < 0.9
         q["u"] = k0["x"] + sx + rng.normal(0, 1.5, nq).astype(np.float32)
         q["v"] = k0["y"] + sy + rng.normal(0, 1.5, nq).astype(np.float32)
-        th = float(rng.choice([3, 7, 15, 30]))
+        th = float(rng.choice([3, 7, 15, 30, 60, 120]))      # 60 / 120: candidate lists beyond 64 entries
         q["radius"] = th * sf[k0["octave"]]
         mode_levels = rng.random()
         q["min_level"] = np.where(mode_levels < 0.6, k0["octave"] - 1, np.where(mode_levels < 0.8, k0["octave"], 0))
