@@ -418,6 +418,8 @@ __global__ __launch_bounds__(256) void k_pyr_rows(uint8_t *__restrict__ pyr, uin
 }
 
 constexpr int kSubMax = 72;              // max (wCell+6), (hCell+6)
+constexpr int kFastStageU = 12;         // k_fast_cells: row groups per staging batch (48 rows of a stride <= 16 dwords)
+constexpr int kFastLdsPerCu = 160 * 1024;  // gfx950
 constexpr int kFastLead = 1;             // k_fast_cells: LDS column of sub-image x is x + kFastLead + 4
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
@@ -506,8 +508,7 @@ __device__ __forceinline__ unsigned long long stamp_now()
 }
 
 #ifndef ORBHIP_FAST_WAVES
-#define ORBHIP_FAST_WAVES 6   // resident waves per SIMD: 258-263 us per 172 frames alone against 266-269 at 8; the contended headline does not
-                              // move outside its run-to-run band (tools/ab_build.sh)
+#define ORBHIP_FAST_WAVES 8   // resident waves per SIMD = what the LDS share of bind_geometry admits (32 workgroups per CU)
 #endif
 template <int SW, bool STAMPS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORBHIP_FAST_WAVES, ORBHIP_FAST_WAVES))) void k_fast_cells(const uint8_t *__restrict__ pyr, const FastCell *__restrict__ cells,
@@ -519,10 +520,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORBHIP_FAST_
     constexpr int SS = SB - 8;                 // bytes per score-map row (detection width + 2 halo bytes fit: dw + 2 <= sw - 4)
     constexpr int LPR = SW <= 16 ? 16 : 32;    // lanes per staged row
     constexpr int RPI = 64 / LPR;              // rows per staging instruction
-    constexpr int U = 10;                      // staging loads in flight per lane
+    constexpr int U = kFastStageU;             // staging loads in flight per lane
     uint32_t *simg = lds;                                   // staged sub-image, LDS col 0 = global column gxb - 4
     uint32_t *sscore = simg + P.img_words;                   // score map with a 1-px zero halo
-    unsigned short *slist = reinterpret_cast<unsigned short *>(sscore + P.score_words);  // (y << 7) | col
+    typedef __attribute__((address_space(3))) unsigned short lds_u16;
+    lds_u16 *slist = (lds_u16 *)(sscore + P.score_words);   // (detection row << 8) | detection column
 
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
 #define FAST_STAMP(i) do { if constexpr (STAMPS) { const unsigned long long t_ = stamp_now(); tacc[i] += t_ - tprev; tprev = t_; } } while (0)
@@ -582,148 +584,186 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORBHIP_FAST_
     if (P.dev == 4) { if (lane == 0) cell_cnt[out_cell] = (int)simg[lane] & 0; return; }   // timing floor: + staging
 #endif
 
-    // column groups: group g covers LDS cols 4g..4g+3; valid centre cols [c_lo, c_hi)
-    constexpr int a = kFastLead;                        // every cell is staged with the same lead (bind_geometry)
-    constexpr int c_lo = a + 4 + 3;                     // = 8: the first centre column sits on a dword boundary
-    const int c_hi = c_lo + dw;
-    const int g_lo = c_lo >> 2, g_hi = (c_hi - 1) >> 2;
-    const int ngrp = g_hi - g_lo + 1;
+    // column groups: group g' covers LDS cols 8 + 4g' .. 8 + 4g' + 3; the detection columns are LDS cols [8, 8 + dw)
+    // (every cell is staged with the same lead, bind_geometry: the first centre column sits on a dword boundary)
+    static_assert(kFastLead + 4 + 3 == 8, "the first detection column is LDS column 8");
+    const int ngrp = (dw + 3) >> 2;
     const int nwork = ngrp * dh;                        // (row, group) work items, row-major
-    const uint32_t magic = cd.magic;                    // ceil(2^20 / ngrp): exact floor(i / ngrp) for i < 4096
-    const int fj = c_lo & 3, lj = (c_hi - 1) & 3;       // first valid pixel of group g_lo, last valid pixel of group g_hi
+    const uint32_t magic = cd.magic;                    // ceil(2^18 / ngrp): floor(i / ngrp) = (4 i * magic) >> 20 for i < 4096
+    const int lj = (dw - 1) & 3;                        // last valid pixel of a row's last group
     const uint8_t *img8 = reinterpret_cast<const uint8_t *>(simg);
     uint8_t *score8 = reinterpret_cast<uint8_t *>(sscore);
     uint32_t *out = cell_kp + out_cell * P.slot_cap;
-    const int kpx = cd.kpx, kpy = cd.kpy;               // keypoint = (col + kpx, y + kpy) relative to (minBorderX, minBorderY)
+    const int kpx = cd.kpx + 8, kpy = cd.kpy;           // keypoint = (entry column + kpx, y + kpy) relative to (minBorderX, minBorderY)
+    // list entry of a pixel: (y << 8) | (4 g' + j) = (detection row << 8) | detection column.  With it4 = 4 * item:
+    //   entry of pixel 0 = y * K1 + it4,  LDS byte address of the item's dword (row y, LDS col 8 + 4 g') = entry - y * K2 + 8
+    const int K1 = 256 - 4 * ngrp;
+    constexpr int K2 = 256 - SB;
+    const uint32_t last4 = 4u * (uint32_t)(ngrp - 1);
+    // pixels of a row's last group beyond the detection rectangle
+    unsigned long long en[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // built by an opaque instruction: the compiler would re-derive the masks from lj inside the loop
+        unsigned half;
+        asm("s_ashr_i32 %0, %1, 31" : "=s"(half) : "s"(lj - j) : "scc");      // j > lj ? ~0 : 0
+        en[j] = ((unsigned long long)half << 32) | half;
+    }
+    // The survivor list holds P.list_cap entries -- far fewer than the cell has pixels, so that 8 wavefronts per SIMD fit
+    // the LDS.  It is the LAST array of the workgroup's LDS: entries past the end fall outside the allocation and are
+    // dropped by the hardware's LDS range check.  A round whose survivor count exceeds the capacity is repeated in bands
+    // of rows that cannot overflow (4 * ngrp pixels per row); banded rounds leave their corners in the score map only and
+    // the NMS walks the map instead of the corner list.
+    const int band_items = (P.list_cap / (4 * ngrp)) * ngrp;
     int total = 0;
     for (int pass = 0; pass < 2; ++pass) {
         // the reference calls FAST(iniThFAST) first and FAST(minThFAST) only for cells that kept nothing (:809-816)
         const int tmin = pass ? P.min_th : P.ini_th;
-        const uint32_t To = (uint32_t)tmin * 0x01000100u, Te = (uint32_t)tmin * 0x00010001u;
-        // ---- dense compass pre-test, survivors -> slist in row-major order ----
-        int nsurv = 0;
-        for (int it0 = 0; it0 < nwork; it0 += 64) {
-            // items past the end (last iteration) recompute the last item and are masked out of the result
-            const int itr = it0 + lane;
-            const uint32_t it = (uint32_t)min(itr, nwork - 1);
-            const int y = (int)(mulu24_s(it, magic) >> 20);           // detection row; sub-image row y + 3
-            const int g = madi24_s(y, -ngrp, (int)it) + g_lo;
-            const uint32_t *p = simg + (madi24(y, SW, g));
-            const uint32_t up = p[0], c0 = p[3 * SW - 1], c1 = p[3 * SW], c2 = p[3 * SW + 1], dn = p[6 * SW];
-            const uint32_t e4 = __builtin_amdgcn_alignbyte(c2, c1, 3);    // ring pixel 4  (x+3)
-            const uint32_t e12 = __builtin_amdgcn_alignbyte(c1, c0, 1);   // ring pixel 12 (x-3)
-            // every comparison is ballot()ed on its own (v_cmp writes the lane mask directly) and the masks are combined as
-            // 64-bit integers on the scalar unit; combining bools first makes the compiler round-trip through VGPRs
-            unsigned long long mb[4], md[4];
+        // thresholds of the packed test: pixels 1, 3 sit in the HIGH byte of their 16-bit lane (t * 256), pixels 0, 2 are
+        // exact; the high lane compares as a 32-bit number whose low half only breaks ties (passes, never drops)
+        const uint32_t Tn_lo = (uint32_t)tmin << 8, Tn_hi = ((uint32_t)tmin << 24) | 0xffffu;
+        const uint32_t Te_lo = (uint32_t)tmin, Te_hi = ((uint32_t)tmin << 16) | 0xffffu;
+        int tv;                                      // tmin in a VGPR: an SGPR operand makes a vector instruction slow
+        asm("v_mov_b32 %0, %1" : "=v"(tv) : "s"(tmin));
+        int band_lo = 0, band_hi = nwork, ncorn = 0;
+        bool banded = false;
+        for (;;) {
+            // ---- dense compass pre-test over items [band_lo, band_hi), survivors -> slist in row-major order ----
+            int nsurv = 0;
+            uint32_t it4 = 4u * (uint32_t)(band_lo + lane);
+            const uint32_t lim4 = 4u * (uint32_t)band_hi;
+            for (int it0 = band_lo; it0 < band_hi; it0 += 64, it4 += 256) {
+                // lanes past the end compute on rows below the detection rectangle (inside the LDS) and are masked out
+                const int y = (int)(mulu24_s(it4, magic) >> 20);          // detection row; sub-image row y + 3
+                const int ent = madi24_s(y, K1, (int)it4);
+                const uint8_t *pb = img8 + madi24(y, -K2, ent);
+                const uint32_t up = *reinterpret_cast<const uint32_t *>(pb + 8),
+                               c0 = *reinterpret_cast<const uint32_t *>(pb + 3 * SB + 4),
+                               c1 = *reinterpret_cast<const uint32_t *>(pb + 3 * SB + 8),
+                               c2 = *reinterpret_cast<const uint32_t *>(pb + 3 * SB + 12),
+                               dn = *reinterpret_cast<const uint32_t *>(pb + 6 * SB + 8);
+                const uint32_t e4 = __builtin_amdgcn_alignbyte(c2, c1, 3);    // ring pixel 4  (x+3)
+                const uint32_t e12 = __builtin_amdgcn_alignbyte(c1, c0, 1);   // ring pixel 12 (x-3)
+                // a bright arc of 9 holds p0 or p8 and p4 or p12, all brighter than v + t; a dark arc the mirror image:
+                // candidate <=> max(A - v, v - B) > t with A = min(max(p0, p8), max(p4, p12)), B = max(min, min).  Each
+                // comparison writes its lane mask directly (v_cmp -> SGPR pair); masks combine on the scalar unit.
+                unsigned long long m[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {   // h = 0: pixels 1, 3 (high bytes, low byte is noise); h = 1: pixels 0, 2 (exact)
-                const uint32_t mk = h ? 0x00ff00ffu : 0xffffffffu;
-                const u16x2_v v = as_u16x2(c1 & mk), q0 = as_u16x2(dn & mk), q8 = as_u16x2(up & mk),
-                              q4 = as_u16x2(e4 & mk), q12 = as_u16x2(e12 & mk);
-                // a bright arc of 9 holds p0 or p8 and p4 or p12, all brighter than v + t; a dark arc the mirror image
-                const uint32_t A = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(q0, q8), __builtin_elementwise_max(q4, q12)));
-                const uint32_t B = as_u32(__builtin_elementwise_max(__builtin_elementwise_min(q0, q8), __builtin_elementwise_min(q4, q12)));
-                const uint32_t vT = as_u32(__builtin_elementwise_add_sat(v, as_u16x2(h ? Te : To)));
-                const uint32_t vmT = as_u32(__builtin_elementwise_sub_sat(v, as_u16x2(h ? Te : To)));
-                // low word: 16-bit compare; high word: 32-bit compare (the low word only breaks ties -> passes, never drops)
-                mb[1 - h] = __builtin_amdgcn_ballot_w64((unsigned short)A > (unsigned short)vT);
-                md[1 - h] = __builtin_amdgcn_ballot_w64((unsigned short)B < (unsigned short)vmT);
-                mb[3 - h] = __builtin_amdgcn_ballot_w64(A > vT);
-                md[3 - h] = __builtin_amdgcn_ballot_w64(B < vmT);
+                for (int h = 0; h < 2; ++h) {   // h = 0: pixels 1, 3 (high bytes, low byte is noise); h = 1: pixels 0, 2 (exact)
+                    const uint32_t mk = h ? 0x00ff00ffu : 0xffffffffu;
+                    const u16x2_v v = as_u16x2(c1 & mk), q0 = as_u16x2(dn & mk), q8 = as_u16x2(up & mk),
+                                  q4 = as_u16x2(e4 & mk), q12 = as_u16x2(e12 & mk);
+                    const u16x2_v A = __builtin_elementwise_min(__builtin_elementwise_max(q0, q8), __builtin_elementwise_max(q4, q12));
+                    const u16x2_v B = __builtin_elementwise_max(__builtin_elementwise_min(q0, q8), __builtin_elementwise_min(q4, q12));
+                    const uint32_t M = as_u32(__builtin_elementwise_max(__builtin_elementwise_sub_sat(A, v), __builtin_elementwise_sub_sat(v, B)));
+                    m[1 - h] = __builtin_amdgcn_ballot_w64((unsigned short)M > (unsigned short)(h ? Te_lo : Tn_lo));
+                    m[3 - h] = __builtin_amdgcn_ballot_w64(M > (h ? Te_hi : Tn_hi));
+                }
+                const unsigned long long mlive = __builtin_amdgcn_ballot_w64(it4 < lim4),
+                                         mlast = __builtin_amdgcn_ballot_w64((uint8_t)ent == (uint8_t)last4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] &= j ? mlive & ~(en[j] & mlast) : mlive;      // pixel 0 of a group is always inside
+                // ordered append: lane-major, then pixel = row-major (y, x), the order the reference emits keypoints in; every
+                // later compaction is stable, so the final list needs no sorting
+                int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m[0] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[0], (unsigned)nsurv));
+#pragma unroll
+                for (int j = 1; j < 4; ++j)
+                    pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[j], (unsigned)pos));
+                nsurv += __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
+                lds_u16 *dst = slist + pos;
+                uint32_t ev = (uint32_t)ent;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(m[j])) {
+                        *dst = (unsigned short)ev;
+                        asm("v_add_u32 %0, 2, %0" : "+v"(dst));     // ++dst, in place (the compiler adds into a copy)
+                    }
+                    ++ev;
+                }
             }
-            // validity of pixel j of this lane's group: only the first / last group of a row is partial
-            const unsigned long long mlive = __builtin_amdgcn_ballot_w64(itr < nwork),
-                                     mfirst = __builtin_amdgcn_ballot_w64(g == g_lo), mlast = __builtin_amdgcn_ballot_w64(g == g_hi);
-            unsigned long long m[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                m[j] = (mb[j] | md[j]) & mlive & ~((j < fj ? mfirst : 0ull) | (j > lj ? mlast : 0ull));
-            // ordered append: lane-major, then pixel = row-major (y, x), the order the reference emits keypoints in; every
-            // later compaction is stable, so the final list needs no sorting
-            int pos[4];
-            pos[0] = __builtin_amdgcn_mbcnt_hi((unsigned)(m[0] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[0], (unsigned)nsurv));
-#pragma unroll
-            for (int j = 1; j < 4; ++j)
-                pos[0] = __builtin_amdgcn_mbcnt_hi((unsigned)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[j], (unsigned)pos[0]));
-#pragma unroll
-            for (int j = 1; j < 4; ++j) pos[j] = add_lane_bit(pos[j - 1], m[j - 1]);
-            nsurv += __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
-            const uint32_t ent = (uint32_t)((y << 7) | (g << 2));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (__builtin_amdgcn_inverse_ballot_w64(m[j])) slist[pos[j]] = (unsigned short)(ent + j);
-        }
-        __syncthreads();
-        FAST_STAMP(2);   // dense pre-test + compaction
+            __syncthreads();
+            FAST_STAMP(2);   // dense pre-test + compaction
+            if (nsurv > P.list_cap) {   // first round only: a band cannot overflow
+                banded = true; band_hi = band_items;
+                continue;
+            }
 
-        // ---- score of the survivors; corners at this threshold -> score map + slist (in place) ----
-        int ncorn = 0;
-        for (int i0 = 0; i0 < nsurv; i0 += 64) {
-            const int i = i0 + lane;
-            const bool act = i < nsurv;
-            const unsigned e = slist[min(i, nsurv - 1)];
-            const int y = e >> 7, col = e & 127;
-            const uint8_t *w = img8 + (madi24(y, SB, col) - 3);   // top-left pixel of the 7x7 window
-            const int v = w[3 * SB + 3];
-            int pr[16];
-            pr[0] = w[6 * SB + 3];  pr[1] = w[6 * SB + 4];  pr[2] = w[5 * SB + 5];  pr[3] = w[4 * SB + 6];
-            pr[4] = w[3 * SB + 6];  pr[5] = w[2 * SB + 6];  pr[6] = w[1 * SB + 5];  pr[7] = w[4];
-            pr[8] = w[3];           pr[9] = w[2];           pr[10] = w[1 * SB + 1]; pr[11] = w[2 * SB];
-            pr[12] = w[3 * SB];     pr[13] = w[4 * SB];     pr[14] = w[5 * SB + 1]; pr[15] = w[6 * SB + 2];
-            const int Ab = min(max(pr[0], pr[8]), max(pr[4], pr[12])), Bd = max(min(pr[0], pr[8]), min(pr[4], pr[12]));
-            const bool brc = Ab > v + tmin, dkc = Bd < v - tmin;
-            // not a bright candidate: a bright arc is impossible (<= t), so the dark network alone gives S (or rejects)
-            const int sgn = brc ? 1 : -1, nv = brc ? -v : v;
-            int d[16];
+            // ---- score of the survivors; corners at this threshold -> score map (+ slist, in place, unless banded) ----
+            for (int i0 = 0; i0 < nsurv; i0 += 64) {
+                const int i = i0 + lane;
+                const bool act = i < nsurv;
+                const unsigned e = slist[min(i, nsurv - 1)];
+                const int y = e >> 8, colr = e & 255;
+                const uint8_t *w = img8 + (madi24(y, SB, colr) + 5);   // top-left pixel of the 7x7 window: LDS col (8 + colr) - 3
+                const int v = w[3 * SB + 3];
+                int pr[16];
+                pr[0] = w[6 * SB + 3];  pr[1] = w[6 * SB + 4];  pr[2] = w[5 * SB + 5];  pr[3] = w[4 * SB + 6];
+                pr[4] = w[3 * SB + 6];  pr[5] = w[2 * SB + 6];  pr[6] = w[1 * SB + 5];  pr[7] = w[4];
+                pr[8] = w[3];           pr[9] = w[2];           pr[10] = w[1 * SB + 1]; pr[11] = w[2 * SB];
+                pr[12] = w[3 * SB];     pr[13] = w[4 * SB];     pr[14] = w[5 * SB + 1]; pr[15] = w[6 * SB + 2];
+                const int Ab = min(max(pr[0], pr[8]), max(pr[4], pr[12])), Bd = max(min(pr[0], pr[8]), min(pr[4], pr[12]));
+                const bool brc = Ab > v + tv, dkc = Bd < v - tv;
+                // not a bright candidate: a bright arc is impossible (<= t), so the dark network alone gives S (or rejects).
+                // The min network runs on x = p (bright) or ~p = -p - 1 (dark): min over an arc commutes with the constant
+                // shift by v, so S = max_k min_arc(x) + (bright ? ~v : v) -- one xor per ring pixel instead of a multiply-add
+                const int s = brc ? 0 : -1;
+                int d[16];
 #pragma unroll
-            for (int kx = 0; kx < 16; ++kx) d[kx] = madi24(pr[kx], sgn, nv);
-            int m3v[16];
+                for (int kx = 0; kx < 16; ++kx) d[kx] = pr[kx] ^ s;
+                int m3v[16];
 #pragma unroll
-            for (int kx = 0; kx < 16; ++kx) m3v[kx] = min3i(d[kx], d[(kx + 1) & 15], d[(kx + 2) & 15]);
-            int best = -512;
-#pragma unroll
-            for (int kx = 0; kx < 16; kx += 2) {
-                const int q0 = min3i(m3v[kx], m3v[(kx + 3) & 15], m3v[(kx + 6) & 15]);
-                const int q1 = min3i(m3v[kx + 1], m3v[(kx + 4) & 15], m3v[(kx + 7) & 15]);
-                best = max3i(best, q0, q1);
-            }
-            if (__any(brc & dkc)) {   // both polarities pass the compass test: evaluate the dark one as well
-                int M3v[16];
-#pragma unroll
-                for (int kx = 0; kx < 16; ++kx) M3v[kx] = max3i(d[kx], d[(kx + 1) & 15], d[(kx + 2) & 15]);
-                int worst = 512;
+                for (int kx = 0; kx < 16; ++kx) m3v[kx] = min3i(d[kx], d[(kx + 1) & 15], d[(kx + 2) & 15]);
+                int best = -512;
 #pragma unroll
                 for (int kx = 0; kx < 16; kx += 2) {
-                    const int q0 = max3i(M3v[kx], M3v[(kx + 3) & 15], M3v[(kx + 6) & 15]);
-                    const int q1 = max3i(M3v[kx + 1], M3v[(kx + 4) & 15], M3v[(kx + 7) & 15]);
-                    worst = min3i(worst, q0, q1);
+                    const int q0 = min3i(m3v[kx], m3v[(kx + 3) & 15], m3v[(kx + 6) & 15]);
+                    const int q1 = min3i(m3v[kx + 1], m3v[(kx + 4) & 15], m3v[(kx + 7) & 15]);
+                    best = max3i(best, q0, q1);
                 }
-                if (brc & dkc) best = max(best, -worst);
+                int sc = best + ~(v ^ s);                 // cornerScore; corner at t <=> S >= t
+                if (__any(brc & dkc)) {   // both polarities pass the compass test: evaluate the dark one as well (d = p there)
+                    int M3v[16];
+#pragma unroll
+                    for (int kx = 0; kx < 16; ++kx) M3v[kx] = max3i(d[kx], d[(kx + 1) & 15], d[(kx + 2) & 15]);
+                    int worst = 512;
+#pragma unroll
+                    for (int kx = 0; kx < 16; kx += 2) {
+                        const int q0 = max3i(M3v[kx], M3v[(kx + 3) & 15], M3v[(kx + 6) & 15]);
+                        const int q1 = max3i(M3v[kx + 1], M3v[(kx + 4) & 15], M3v[(kx + 7) & 15]);
+                        worst = min3i(worst, q0, q1);
+                    }
+                    if (brc & dkc) sc = max(sc, v - worst - 1);
+                }
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(sc >= tmin) & __builtin_amdgcn_ballot_w64(act);
+                if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                    score8[madi24(y, SS, colr) + (SS + 1)] = (uint8_t)sc;         // score column = detection x + 1, row y + 1
+                    if (!banded) slist[ncorn + lane_prefix(m)] = (unsigned short)e;   // write index <= read index: in place is safe
+                }
+                ncorn += __popcll(m);
             }
-            const int sc = best - 1;                  // cornerScore; corner at t <=> S >= t
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(sc >= tmin) & __builtin_amdgcn_ballot_w64(act);
-            if (__builtin_amdgcn_inverse_ballot_w64(m)) {
-                score8[madi24(y, SS, col) + (SS - c_lo + 1)] = (uint8_t)sc;   // score column = detection x + 1, row y + 1
-                slist[ncorn + lane_prefix(m)] = (unsigned short)e;            // write index <= read index: in place is safe
-            }
-            ncorn += __popcll(m);
+            __syncthreads();
+            FAST_STAMP(3);   // score network
+            if (!banded) break;
+            band_lo = band_hi;
+            if (band_lo >= nwork) break;
+            band_hi = min(nwork, band_lo + band_items);
         }
-        __syncthreads();
-        FAST_STAMP(3);   // score network
 
-        // ---- NMS over the corner list + emission (row-major already) ----
+        // ---- NMS over the corner list (banded rounds: over every pixel of the score map) + emission, row-major already ----
         int nfin = 0;
-        for (int i0 = 0; i0 < ncorn; i0 += 64) {
-            const int i = i0 + lane;
-            const unsigned e = slist[min(i, ncorn - 1)];
-            const int y = e >> 7, col = e & 127;
-            const uint8_t *s = score8 + (madi24(y, SS, col) - c_lo);   // top-left neighbour
+        const int ncand = banded ? dw * dh : ncorn;
+        for (int i0 = 0; i0 < ncand; i0 += 64) {
+            const int i = i0 + lane, ic = min(i, ncand - 1);
+            int y, colr;
+            if (banded) { y = ic / dw; colr = ic - y * dw; }
+            else { const unsigned e = slist[ic]; y = e >> 8; colr = e & 255; }
+            const uint8_t *s = score8 + madi24(y, SS, colr);           // top-left neighbour
             const int v = s[SS + 1];
             const int nb = max3i(max3i(s[0], s[1], s[2]), max3i(s[SS], s[SS + 2], s[2 * SS]), max((int)s[2 * SS + 1], (int)s[2 * SS + 2]));
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(i < ncorn) & __builtin_amdgcn_ballot_w64(v > nb);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(i < ncand) & __builtin_amdgcn_ballot_w64(v > nb);
             const int pos = nfin + lane_prefix(m);
             if (__builtin_amdgcn_inverse_ballot_w64(m & __builtin_amdgcn_ballot_w64(pos < P.slot_cap)))
-                out[pos] = (uint32_t)(col + kpx) | ((uint32_t)(y + kpy) << 12) | ((uint32_t)v << 24);
+                out[pos] = (uint32_t)(colr + kpx) | ((uint32_t)(y + kpy) << 12) | ((uint32_t)v << 24);
             nfin += __popcll(m);
         }
         total = nfin;
@@ -1682,7 +1722,7 @@ static FastCell make_fast_cell(const PyrGeom &G, const CellDesc &c, int img_stri
     f.kpx = (short)(c.offx - 4 - a); f.kpy = (short)(c.offy + 3);
     const int dwc = sw - 6, c_lo = a + 7, c_hi = c_lo + dwc;
     const int ngrp = dwc > 0 ? ((c_hi - 1) >> 2) - (c_lo >> 2) + 1 : 1;
-    f.magic = ((1u << 20) + ngrp - 1) / ngrp;
+    f.magic = ((1u << 18) + ngrp - 1) / ngrp;
     return f;
 }
 
@@ -1778,12 +1818,25 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         if (need > 21) { set_error("cell geometry exceeds the FAST kernel limits"); return ORBHIP_E_SIZE; }
         F2.scoreW = F2.strideW - 2;
         F2.score_words = (mdh + 2) * F2.scoreW;
-        F2.list_words = (mdw * mdh + 1) / 2 + 1;           // uint16 list: every pixel may pass the pre-test
         // staging batches write whole row groups: round the image rows up to what they touch
         {
-            const int lpr = F2.strideW <= 16 ? 16 : 32, rpi = 64 / lpr, rows_batch = rpi * 10;
+            const int lpr = F2.strideW <= 16 ? 16 : 32, rpi = 64 / lpr, rows_batch = rpi * kFastStageU;
             const int rows = ((msh + rows_batch - 1) / rows_batch) * rows_batch;
             F2.img_words = rows * F2.strideW;
+        }
+        // uint16 survivor list.  Every pixel of a cell may pass the pre-test, but few do: the list gets what is left of the
+        // LDS share that lets 32 workgroups (8 wavefronts per SIMD) live on a CU -- or of the next larger share that holds
+        // 128 entries and a whole row of the widest cell -- and the kernel repeats a round that overflows in row bands
+        {
+            const int full = mdw * mdh, row_px = 4 * ((mdw + 3) >> 2), fixed = (F2.img_words + F2.score_words) * 4;
+            int cap = full;
+            for (int wgs = 32; wgs >= 4; wgs -= 4) {
+                const int share = (kFastLdsPerCu / wgs) & ~511;            // LDS is handed out in 512-byte granules
+                const int room = (share - fixed) / 2 - 2;
+                if (room >= std::max(128, row_px)) { cap = std::min(full, room); break; }
+            }
+            F2.list_cap = cap;
+            F2.list_words = (cap + 1) / 2 + 1;
         }
         e->fast_lds_bytes = (F2.img_words + F2.score_words + F2.list_words) * 4;
         e->cells2.clear();
@@ -1791,7 +1844,7 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         e->cells_stride = 0;
         FastParams &FP = e->fast_params;
         memset(&FP, 0, sizeof(FP));
-        FP.img_words = F2.img_words; FP.score_words = F2.score_words;
+        FP.img_words = F2.img_words; FP.score_words = F2.score_words; FP.list_cap = F2.list_cap;
         FP.ini_th = G.ini_th; FP.min_th = G.min_th;
     }
     G.frame_bytes = off;

@@ -14,11 +14,12 @@ struct FastLds {
     int strideW;      // row stride in dwords (odd) = the kernel's template argument: staged dwords + one real dword on the left
     int scoreW;       // score-map row stride in dwords (= strideW - 2)
     int img_words, score_words, list_words;
+    int list_cap;     // survivor-list entries (uint16); a round with more survivors is repeated in row bands
 };
 // One FAST cell as k_fast_cells2 wants it: every derived quantity precomputed, one 32-byte scalar load per wavefront
 struct alignas(32) FastCell {
     uint32_t src_off;        // byte offset inside a frame's pyramid block of LDS (row 0, col 0): row y0, column gxb - 4
-    uint32_t magic;          // ceil(2^20 / ngrp)
+    uint32_t magic;          // ceil(2^18 / ngrp), ngrp = four-pixel groups per detection row
     unsigned short pitch;    // row pitch of the level's padded plane
     short kpx, kpy;          // keypoint = (LDS col + kpx, detection row + kpy) relative to (minBorderX, minBorderY)
     unsigned char sw, sh, a; // sub-image size; a = x0 & 3
@@ -28,7 +29,7 @@ struct alignas(32) FastCell {
 static_assert(sizeof(FastCell) == 32, "FastCell is one s_load_dwordx8");
 struct FastParams {
     uint32_t frame_bytes, rcp_cells;
-    int ncells_total, slot_cap, ini_th, min_th, img_words, score_words;
+    int ncells_total, slot_cap, ini_th, min_th, img_words, score_words, list_cap;
     int dev;   // development builds only: timing floors / stamped kernel
 };
 // Tables of the pyramid kernels (k_pyr_base / k_pyr_rows): a wavefront owns kPyrRows padded destination rows (its row

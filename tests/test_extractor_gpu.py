@@ -132,6 +132,48 @@ def test_maximum_quota_and_candidate_pressure(mods):
     assert len(k) > 3000
 
 
+@pytest.mark.parametrize("kind,W,H,scale,nlev,ini,mn", [
+    ("checker3", 1241, 376, 1.2, 8, 20, 7), ("checker3", 640, 480, 1.5, 4, 20, 7), ("noise", 752, 480, 1.2, 8, 20, 7),
+    ("noise", 1241, 376, 1.2, 8, 9, 2), ("mixed", 901, 403, 1.3, 6, 20, 7), ("checker2", 333, 251, 1.2, 5, 30, 10)])
+def test_fast_survivor_list_overflow_runs_in_row_bands(mods, kind, W, H, scale, nlev, ini, mn):
+    """k_fast_cells keeps a survivor list far smaller than a cell (8 wavefronts per SIMD fit the LDS that way) and repeats a
+    round with more survivors in row bands.  Images on which (nearly) EVERY pixel passes the compass pre-test -- a 3-px
+    checkerboard: the four compass pixels of every centre are at the opposite grey level; white noise -- force that path on
+    whole levels; the mixed image has both kinds of cell side by side."""
+    pkg, O = mods
+    rng = np.random.default_rng(19)
+    yy, xx = np.mgrid[0:H, 0:W]
+    p = 3 if kind != "checker2" else 2
+    checker = ((((xx // p) + (yy // p)) & 1) * 180 + 40).astype(np.uint8)
+    noise = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    if kind.startswith("checker"):
+        img = checker
+    elif kind == "noise":
+        img = noise
+    else:
+        img = synth_frame(3, W, H)
+        img[:, W // 3:2 * W // 3] = checker[:, W // 3:2 * W // 3]
+        img[H // 2:, 2 * W // 3:] = noise[H // 2:, 2 * W // 3:]
+    img = np.ascontiguousarray(img)
+    ext = pkg.ORBextractor(3000, scale, nlev, ini, mn)
+    ora = O.OracleExtractor(3000, scale, nlev, ini, mn)
+    k, d = ext(img)
+    ok, od = ora.extract(img)
+    assert_stagewise_equal(ext, ora, nlev, kind)
+    assert_kps_equal(k, ok, kind)
+    assert np.array_equal(d, od)
+    # the same handle on an ordinary frame afterwards, and a lazy level 0 handle on the dense one
+    img2 = synth_frame(5, W, H)
+    k2, d2 = ext(img2)
+    ok2, od2 = ora.extract(img2)
+    assert_kps_equal(k2, ok2, kind + " (ordinary frame after)")
+    assert np.array_equal(d2, od2)
+    ext.set_lazy_level0(True)
+    k3, d3 = ext(img)
+    assert_kps_equal(k3, ok, kind + " (lazy level 0)")
+    assert np.array_equal(d3, od)
+
+
 def test_blur_kernel_is_a_data_table(mods):
     """The 7 blur weights are configuration, not code (OpenCV-version dependent)."""
     pkg, O = mods
