@@ -440,15 +440,18 @@ __device__ __forceinline__ int lane_prefix(unsigned long long m)
 //     pixels is read as two uint16 lanes whose high bytes are pixels 1 and 3 -- the low byte only
 //     perturbs the value by < 1 gray level, which can let a non-corner through (the score re-checks
 //     exactly) but never drops one; pixels 0 and 2 use the same dwords masked with 0x00ff00ff
-//     (exact).  Saturating add/sub give v+t / v-t; the eight comparisons write lane masks directly
-//     (v_cmp -> SGPR pair), the masks are combined on the scalar unit, and the ordered survivor
-//     compaction is one v_mbcnt chain + carry-in adds.
+//     (exact).  With A = min(max(p0,p8), max(p4,p12)) and B = max(min(p0,p8), min(p4,p12)) a pixel is
+//     a candidate iff max(A - v, v - B) > t (saturating differences): ONE comparison per pixel writes
+//     its lane mask (v_cmp -> SGPR pair), the masks are combined on the scalar unit, the ordered
+//     survivor compaction is one v_mbcnt chain and a running LDS pointer.  The item's row, list entry
+//     and LDS address come from one multiply-shift and two multiply-adds of a strength-reduced counter.
 //  3. the threshold-independent score S = max(dark,bright)-1 (cornerScore<16>) only for survivors:
-//     a survivor's polarity follows from its compass pixels, so the min3 network runs once on
-//     sign-selected differences; a pixel that passes the compass test for both polarities (0.3 %
-//     of the survivors) takes the max3 network too, under a wave-uniform branch.  Exactness: a
-//     brighter and a darker arc of 9 cannot coexist on a ring of 16, so at most one polarity
-//     exceeds t and the other one is <= t < S.
+//     a survivor's polarity follows from its compass pixels, so the min3 network runs once, on x = p
+//     (bright) or x = ~p (dark): the centre value only shifts an arc's minimum, it is added at the end
+//     (S = max_k min_arc(x) + (bright ? ~v : v)); a pixel that passes the compass test for both
+//     polarities (0.3 % of the survivors) takes the max3 network too, under a wave-uniform branch.
+//     Exactness: a brighter and a darker arc of 9 cannot coexist on a ring of 16, so at most one
+//     polarity exceeds t and the other one is <= t < S.
 //  4. NMS (strict maximum over the 8 neighbours; outside the detection rectangle = 0, like the
 //     reference's zero-initialised score rows) over the corner list, fused with the emission.
 //  5. pass 0 runs at iniThFAST; a cell that keeps nothing repeats 2-4 at minThFAST (:809-816).
@@ -1372,18 +1375,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBHIP_DESC
     const uint32_t hitems = hitem_tab[lane];
     uint32_t *win = swin[wv];
     uint4 *hs = shsum[wv];
+  int level = 0, before = 0, mine = 0, kp_base = 0, kp_end = -1, pitch = 0;
   for (int kk = 0; kk < per_wave; ++kk) {
     const int slot = (bx * 4 + wv) * per_wave + kk;  // wave-uniform: everything up to the pixel loads is scalar work
     if (slot >= G.kp_cap_total) break;
-    int level = 0;
-    for (int l = 1; l < G.nlevels; ++l) if (slot >= G.lv[l].kp_base) level = l;
-    int before = 0, mine = 0;
-    for (int l = 0; l < G.nlevels; ++l) {
-        const int c = cnts[l];
-        if (l < level) before += c;
-        if (l == level) mine = c;
+    // level of the slot, keypoints of the levels before it and of its own.  The slots of a wavefront are consecutive, so
+    // the search over the level table (230 scalar instructions and 16 dependent scalar loads through the kernel argument;
+    // the scalar pipe of this kernel is as busy as the vector pipe) runs again only when a slot leaves the level of the
+    // one before it: 72.4 -> 68.3 us per 64 frames.  Folding the whole table with static indices before the loop (one
+    // wait for all loads) measured the same and costs 14 more spilled SGPRs
+    if (slot >= kp_end) {
+        level = 0;
+        for (int l = 1; l < G.nlevels; ++l) if (slot >= G.lv[l].kp_base) level = l;
+        before = 0; mine = 0;
+        for (int l = 0; l < G.nlevels; ++l) {
+            const int c = cnts[l];
+            if (l < level) before += c;
+            if (l == level) mine = c;
+        }
+        kp_base = G.lv[level].kp_base; kp_end = kp_base + G.lv[level].kp_cap; pitch = G.lv[level].pitch;
     }
-    const int kp_base = G.lv[level].kp_base, pitch = G.lv[level].pitch;
     const int i = slot - kp_base;
     if (i >= mine) continue;
     const int oidx = before + i;
