@@ -1481,8 +1481,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBHIP_DESC
     // is evaluated right at the 8 sample points of a lane (4 dwords of row sums -- two window rows each -- against the
     // tap pairs of the point's row parity) instead of over all 37 x 37 patch pixels first ----
     const uint32_t *hd = reinterpret_cast<const uint32_t *>(hs);   // row sums as dwords: [pair-row][column], 40 columns
-    auto blurred = [&](int r, int c) -> int {
-        const int R = r + 18, C = c + 18;                  // patch row / column; window rows R .. R + 6
+    // cvRound of a rotated pattern coordinate plus 18, the patch index: adding 1.5 * 2^23 rounds the sum to an integer --
+    // to nearest, ties to even, exactly what v_rndne / lrint do, for |t| < 2^22 -- and leaves it in the low mantissa bits:
+    // two full-rate instructions (v_add_f32, v_sub_u32 with the + 18 folded in) instead of v_rndne + v_cvt_i32 + v_add
+    auto round18 = [](float t) -> int {
+        return (int)(__float_as_uint(__fadd_rn(t, 12582912.0f)) - (0x4B400000u - 18u));
+    };
+    auto blurred = [&](int R, int C) -> int {             // patch row / column; window rows R .. R + 6
         const uint32_t *p = hd + madi24(R >> 1, kHGroups * 4, C);
         const uint32_t d0 = p[0], d1 = p[kHGroups * 4], d2 = p[2 * kHGroups * 4], d3 = p[3 * kHGroups * 4];
         const bool odd = (R & 1) != 0;
@@ -1495,10 +1500,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBHIP_DESC
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float px0 = pat[j].x, py0 = pat[j].y, px1 = pat[j].z, py1 = pat[j].w;
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, bsn), __fmul_rn(py0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, bsn)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, bsn), __fmul_rn(py1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, bsn)));
+        const int r0 = round18(__fadd_rn(__fmul_rn(px0, bsn), __fmul_rn(py0, a)));
+        const int c0 = round18(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, bsn)));
+        const int r1 = round18(__fadd_rn(__fmul_rn(px1, bsn), __fmul_rn(py1, a)));
+        const int c1 = round18(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, bsn)));
         t0v[j] = blurred(r0, c0);
         t1v[j] = blurred(r1, c1);
     }
