@@ -796,10 +796,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORBHIP_FAST_
 // list order (new children reversed in front, survivors behind) and relabels keys.
 // ---------------------------------------------------------------------------
 constexpr int kOctU = 4;            // independent keys per thread in the key loops
-// keys held in LDS (36 KB for the 512-node variant, 12 KB for the 2048-node one, whose node tables are 4x larger); levels
-// with more candidates use the HBM workspace
-template <int MAXN> constexpr int oct_keys_lds() { return MAXN <= 512 ? 6144 : 2048; }
-
+// The candidate keys and their owning nodes live in the HBM workspace (L2-resident while a workgroup works on them), not
+// in LDS: with them the workgroup needed 70 KB and two fitted a CU; at 34 KB four do, which is what hides the latencies
+// of this kernel -- 170 frames alone 98 -> 84 us, three pipelines 278.8 -> 283.4 k frames/s; a single frame and a
+// 64-frame batch measure the same either way.
 template <int MAXN>
 struct OctShared {
     short x0[2][MAXN], x1[2][MAXN], y0[2][MAXN], y1[2][MAXN];
@@ -812,11 +812,9 @@ struct OctShared {
     int cincl[MAXN];           // inclusive scan of child counts in processing order
     int scan[16];
     int vars[8];
-    uint32_t lkeys[oct_keys_lds<MAXN>()];        // candidate keys (x | y<<12 | score<<24) when they fit
-    unsigned short lnode[oct_keys_lds<MAXN>()];  // owning node of each key
 };
 
-template <int MAXN, bool INLDS, int T>
+template <int MAXN, int T>
 __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G, const LevelGeom &L,
                                             const int level, const int b, const int K,
                                             const int *__restrict__ ccnt_in, const uint32_t *__restrict__ ckp_in,
@@ -824,8 +822,8 @@ __device__ __forceinline__ void octree_body(OctShared<MAXN> &S, const PyrGeom &G
                                             uint32_t *__restrict__ sel_kp, int *__restrict__ sel_cnt,
                                             int *__restrict__ frame_status)
 {
-#define keys(k) (*(INLDS ? &S.lkeys[k] : &gkeys[k]))
-#define knode(k) (*(INLDS ? &S.lnode[k] : &gnode[k]))
+#define keys(k) gkeys[k]        // candidate keys (x | y<<12 | score<<24)
+#define knode(k) gnode[k]      // owning node of each key
     const int tid = threadIdx.x;
     const int N = L.quota;
     // ---- initial nodes (:543-585); their key counters live in counter buffer 1 (buffer 0 holds the cell offsets) ----
@@ -1176,10 +1174,7 @@ __global__ __launch_bounds__(T) void k_octree(PyrGeom G, const int *__restrict__
         if (c < L.ncells) S.ccnt[0][c] = K + base;  // ncells <= MAXN*4 checked on the host
         K += tot;
     }
-    if (K <= oct_keys_lds<MAXN>())
-        octree_body<MAXN, true, T>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
-    else
-        octree_body<MAXN, false, T>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
+    octree_body<MAXN, T>(S, G, L, level, b, K, ccnt_in, ckp_in, gkeys, gnode, sel_kp, sel_cnt, frame_status);
 }
 
 // ---------------------------------------------------------------------------
@@ -1882,6 +1877,9 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
         int max_cells = 0;
         for (int l = 0; l < e->nlevels; ++l) max_cells = std::max(max_cells, G.lv[l].ncells);
         e->octree_threads = max_cells >= 128 ? 512 : 256;
+#ifdef ORBHIP_EXP_OCT_T
+        e->octree_threads = ORBHIP_EXP_OCT_T;
+#endif
     }
     if (maxn <= 512) e->octree_maxn = 512;
     else if (maxn <= 2048) e->octree_maxn = 2048;
