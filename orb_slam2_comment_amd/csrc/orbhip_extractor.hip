@@ -580,7 +580,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORBHIP_FAST_
             }
         }
     }
-    for (int i = lane; i < (dh + 2) * (SS / 4); i += 64) sscore[i] = 0;
+    // score-map clear, 16 bytes per lane (the map starts on a 16-byte boundary: img_words is a multiple of 4; the last
+    // store may run a few bytes into the survivor list, which nothing has written yet)
+    for (int i = lane; i < ((dh + 2) * SS + 15) / 16; i += 64) reinterpret_cast<uint4 *>(sscore)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     FAST_STAMP(1);   // staging (global -> LDS) + score-map clear
 #ifdef ORBHIP_DEVTOOLS
@@ -1292,8 +1294,6 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     }
 }
 
-constexpr int kDescPerWave = 2;  // consecutive keypoint slots per wavefront (1: 86 us, 2: 64 us, 3: 79 us, 4: 79 us per 64 frames)
-
 // ---------------------------------------------------------------------------
 // K5+K6+K7 fused: IC_Angle + GaussianBlur(7x7) of the patch + steered rBRIEF, one wavefront per keypoint.
 // The blurred level is only ever read inside the 37 x 37 patch of a keypoint (:108-147), so the wavefront blurs that
@@ -1323,6 +1323,20 @@ constexpr int kHPairs = 22, kHGroups = 10;    // row-pass results: 22 pair-rows 
                               // pipelines (no gate) preferred 5 (244-248 k against 235-246 k): fewer descriptor waves left the
                               // other pipelines' kernels room
 #endif
+// Consecutive keypoint slots per wavefront of k_describe_fused (a launch argument).  More slots amortise the wavefront's
+// start-up (tables, level search) but leave fewer wavefronts to fill the GPU's 7 x 1024 slots evenly: per 64 frames alone
+// 1: 86 us, 2: 64 us, 3: 79 us, 4: 79 us (4.6 rounds of wavefronts at 2, 3.1 / 2.3 at 3 / 4); per 170 frames alone 2, 3
+// and 4 measure the same (162-164 us) and three pipelines prefer 4 (282.5 / 286.0 / 286.6 k frames/s).  The launch takes
+// the largest count that still leaves kDescMinRounds rounds.
+constexpr int kDescWaveSlotsPerCu = 4 * ORBHIP_DESC_WAVES, kDescMinRounds = 6;
+static int desc_per_wave(int kp_cap_total, int batch, int num_cus)
+{
+    const double slots = (double)num_cus * kDescWaveSlotsPerCu;
+    for (int p = 4; p > 2; --p)
+        if ((double)kp_cap_total * batch / p >= kDescMinRounds * slots) return p;
+    return 2;
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBHIP_DESC_WAVES, ORBHIP_DESC_WAVES))) void k_describe_fused(const uint8_t *__restrict__ pyr, PyrGeom G,
                                                         const uint32_t *__restrict__ sel_kp,
                                                         const int *__restrict__ sel_cnt,
@@ -1873,13 +1887,10 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
     G.cand_cap_total = std::max(cand_base, 1);
     {   // workgroup size of the octree kernel: the level-0 workgroup is the critical path (all (level, frame) workgroups
         // are co-resident); 512 threads halve its key loops (61 -> 54 us per 64 KITTI frames), 1024 would leave one
-        // workgroup per CU (75 us)
+        // workgroup per CU (75 us).  Re-measured with the keys in HBM under three pipelines: 256 and 512 level, 1024 -4.5 %
         int max_cells = 0;
         for (int l = 0; l < e->nlevels; ++l) max_cells = std::max(max_cells, G.lv[l].ncells);
         e->octree_threads = max_cells >= 128 ? 512 : 256;
-#ifdef ORBHIP_EXP_OCT_T
-        e->octree_threads = ORBHIP_EXP_OCT_T;
-#endif
     }
     if (maxn <= 512) e->octree_maxn = 512;
     else if (maxn <= 2048) e->octree_maxn = 2048;
@@ -2068,6 +2079,7 @@ static int launch_pipeline(orbhip_extractor *e, const uint8_t *d_images, int bat
     if (sm & 16) {
         // IC_Angle + the 7x7 blur of the keypoint's patch + rBRIEF in one kernel: no blurred plane exists unless
         // orbhip_blurred_level_download asks for one
+        const int kDescPerWave = desc_per_wave(G.kp_cap_total, batch, e->num_cus);
         const dim3 grid((G.kp_cap_total + 4 * kDescPerWave - 1) / (4 * kDescPerWave), batch);
         hipLaunchKernelGGL(k_describe_fused, grid, dim3(256), 0, s, b_pyr, G, b_sel, b_sel_cnt, e->d_desc_tab,
                            e->d_patternf, d_kps, d_desc, cap, d_n, status, kDescPerWave, e->blurw,
@@ -2137,6 +2149,10 @@ int orbhip_extractor_create(int nfeatures, float scale_factor, int nlevels, int 
         return ORBHIP_E_HIP;
     }
     e->stream = e->own_stream;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
+    }
     // orientation disc (IC_Angle, :77-104: rows v = -15 .. 15, columns |u| <= umax[|v|]) cut into the aligned dwords of the
     // descriptor kernel's window tile (row stride 11 dwords, disc centre at row 21, byte column 21): chunk t = (row, dword);
     // lane l owns chunks l, 64 + l, 128 + l, 192 + l (consecutive lanes read consecutive dwords); integer sums do not

@@ -88,6 +88,7 @@ struct orbhip_extractor {
     std::vector<orbhip::FastCell> cells2;
     orbhip::FastCell *d_cells2 = nullptr;
     orbhip::FastParams fast_params;
+    int num_cus = 256;              // compute units of the device (launch shaping)
     orbhip::TileDesc *d_tiles = nullptr;
     int *d_desc_tab = nullptr;      // descriptor kernel tables: disc chunks {dword index, u weights, v weights}[4][64], row-pass items[64]
     bool blur_valid = false;        // d_blur holds the blurred planes of the last batch

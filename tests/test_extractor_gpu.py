@@ -370,6 +370,46 @@ def test_device_entry_with_row_and_frame_strides(mods):
         assert np.array_equal(ext.image_pyramid(1, with_border=True, frame=b), ora.level_padded(1))
 
 
+@pytest.mark.parametrize("B", [136, 200])
+def test_large_device_batches_use_more_keypoint_slots_per_wavefront(mods, B):
+    """k_describe_fused gives a wavefront 2, 3 or 4 consecutive keypoint slots depending on how many wavefronts the launch
+    has (orbhip_extractor.hip, desc_per_wave): 136 frames at nFeatures 1000 take 3, 200 frames 4 -- a level boundary then
+    falls INSIDE a wavefront's slots.  Every frame of the batch must equal the single-frame extraction (2 slots) of the same
+    image and the oracle."""
+    import torch
+    pkg, O = mods
+    H, W, nf = 240, 320, 1000
+    base = [synth_frame(70 + i, W, H) for i in range(5)]
+    frames = np.stack([base[i % 5] for i in range(B)])
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(frames).to(dev)
+    ext = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    cap = ext.capacity(H, W)
+    d_k = torch.zeros((B, cap, 7), dtype=torch.int32, device=dev)
+    d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_s = torch.zeros(B, dtype=torch.int32, device=dev)
+    ext.extract_batch_device(d_img.data_ptr(), B, H, W, d_k.data_ptr(), d_d.data_ptr(), cap, d_n.data_ptr(), d_s.data_ptr())
+    ext.sync()
+    assert int(d_s.abs().sum().item()) == 0
+    n = d_n.cpu().numpy()
+    kps = d_k.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, cap)
+    desc = d_d.cpu().numpy()
+    ora = O.OracleExtractor(nf, 1.2, 8, 20, 7)
+    single = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    ref = []
+    for i in range(5):
+        ok, od = ora.extract(base[i])
+        sk, sd = single(base[i])
+        assert_kps_equal(sk, ok, "single frame %d" % i)
+        assert np.array_equal(sd, od)
+        ref.append((ok, od))
+    for b in range(B):
+        ok, od = ref[b % 5]
+        assert_kps_equal(kps[b, :n[b]], ok, "frame %d of %d" % (b, B))
+        assert np.array_equal(desc[b, :n[b]], od)
+
+
 def test_host_api_graph_replay_is_invalidated_correctly(mods):
     """The host-pointer entry replays a captured hipGraph; every event that changes a captured argument must drop it:
     batch size, capacity (new geometry), image size, blur weights, stream.  Results must not depend on the history."""
