@@ -47,6 +47,20 @@ def main():
         ext.set_lazy_level0(lazy)
         desc += " lazy0" if lazy else ""
         img0, img1 = synth_frame(seed, W, H), synth_frame(seed, W, H, shift_xy=(sx, sy))
+        dense = rng.random()
+        if dense < 0.25:
+            # regions where (nearly) every pixel passes the FAST pre-test -- white noise, a 2- or 3-px checkerboard -- overflow
+            # the kernel's survivor list and take its row-band path; both frames get the same patch (shifted)
+            yy, xx = np.mgrid[0:H, 0:W]
+            per = int(rng.choice([2, 3]))
+            pat = rng.integers(0, 256, (H, W + 16), dtype=np.uint8) if dense < 0.12 else \
+                np.pad(((((xx // per) + (yy // per)) & 1) * int(rng.integers(90, 200)) + 30).astype(np.uint8), ((0, 0), (0, 16)), mode="wrap")
+            x0, x1 = sorted(int(v) for v in rng.integers(0, W, 2)); y0, y1 = sorted(int(v) for v in rng.integers(0, H, 2))
+            x1 = max(x1, min(W, x0 + 60)); y1 = max(y1, min(H, y0 + 60))
+            img0 = img0.copy(); img1 = img1.copy()
+            img0[y0:y1, x0:x1] = pat[y0:y1, x0:x1]
+            img1[y0:y1, x0:x1] = pat[y0:y1, x0 + 3:x1 + 3]
+            desc += " dense[%d:%d,%d:%d]" % (y0, y1, x0, x1)
         try:
             k0, d0 = ext(img0)
         except Exception as e:
