@@ -1496,12 +1496,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ORBHIP_DESC
     auto round18 = [](float t) -> int {
         return (int)(__float_as_uint(__fadd_rn(t, 12582912.0f)) - (0x4B400000u - 18u));
     };
+    uint32_t vw0, vw1, vw2, vw3, vx0, vx1, vx2, vx3;     // even-row tap pairs and their difference to the odd-row ones, in VGPRs
+    asm("v_mov_b32 %0, %1" : "=v"(vw0) : "s"(w01)); asm("v_mov_b32 %0, %1" : "=v"(vx0) : "s"(w01 ^ w0h));
+    asm("v_mov_b32 %0, %1" : "=v"(vw1) : "s"(w23)); asm("v_mov_b32 %0, %1" : "=v"(vx1) : "s"(w23 ^ w12));
+    asm("v_mov_b32 %0, %1" : "=v"(vw2) : "s"(w45)); asm("v_mov_b32 %0, %1" : "=v"(vx2) : "s"(w45 ^ w34));
+    asm("v_mov_b32 %0, %1" : "=v"(vw3) : "s"(w6l)); asm("v_mov_b32 %0, %1" : "=v"(vx3) : "s"(w6l ^ w56));
     auto blurred = [&](int R, int C) -> int {             // patch row / column; window rows R .. R + 6
         const uint32_t *p = hd + madi24(R >> 1, kHGroups * 4, C);
         const uint32_t d0 = p[0], d1 = p[kHGroups * 4], d2 = p[2 * kHGroups * 4], d3 = p[3 * kHGroups * 4];
-        const bool odd = (R & 1) != 0;
-        const uint32_t acc = udot2(d0, odd ? w0h : w01, udot2(d1, odd ? w12 : w23, udot2(d2, odd ? w34 : w45,
-                                   udot2(d3, odd ? w56 : w6l, 32768u))));
+        // tap pairs of the row's parity, selected by mask arithmetic on VGPR copies of the words: v_and + v_xor issue at the
+        // full rate, the v_cmp + four v_cndmask of `odd ? a : b` do not (68.3 -> 67.2 us per 64 frames)
+        const uint32_t om = 0u - (uint32_t)(R & 1);
+        const uint32_t acc = udot2(d0, vw0 ^ (om & vx0), udot2(d1, vw1 ^ (om & vx1), udot2(d2, vw2 ^ (om & vx2),
+                                   udot2(d3, vw3 ^ (om & vx3), 32768u))));
         return min((int)(acc >> 16), 255);                 // the taps sum to 257: saturate like the byte store did
     };
     unsigned long long bits[4];

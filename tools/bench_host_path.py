@@ -4,8 +4,8 @@ host keypoints / descriptors out), straight through the C ABI with preallocated 
 
   python tools/bench_host_path.py [--frames 64] [--reps 20] [--pinned]
 
-Environment switches of the library (read once per process): ORBHIP_NO_PIPELINE=1 (one DMA each way instead of the
-chunk pipeline), ORBHIP_HOST_TIMING=1 (per-phase host timers on stderr).
+A batch of 32 frames or more runs as the library's chunk pipeline (copy in / kernels / copy out on three streams); a
+single frame replays the captured hipGraph.
 """
 import argparse
 import json
@@ -55,7 +55,7 @@ def main():
         call()
         ts.append(time.perf_counter() - t0)
     med = float(np.median(ts))
-    print(json.dumps({"frames": B, "pinned_input": bool(args.pinned), "no_pipeline": "ORBHIP_NO_PIPELINE" in os.environ,
+    print(json.dumps({"frames": B, "pinned_input": bool(args.pinned),
                       "ms_median": round(med * 1e3, 3), "ms_min": round(min(ts) * 1e3, 3), "frames_per_s": round(B / med, 1),
                       "mean_keypoints": round(float(n.mean()), 1)}))
 

@@ -25,6 +25,7 @@ python3 tools/bench_matchers.py > $OUT/matcher_latency.json 2> $OUT/matcher_late
 python3 tools/bench_track_th.py > $OUT/track_th.json 2> $OUT/track_th.err
 timeout -k 5 100 ./tools/micro/valu_rate2 > $OUT/issue_rates.txt 2>&1 || true
 timeout -k 5 100 ./tools/micro/valu_rate3 >> $OUT/issue_rates.txt 2>&1 || true
+timeout -k 5 100 ./tools/micro/valu_rate4 >> $OUT/issue_rates.txt 2>&1 || true
 rm -rf $OUT/stats2 $OUT/stats1
 cat $OUT/bench_final.json
 cat $OUT/host_path.json $OUT/host_path_pinned.json
