@@ -2190,6 +2190,8 @@ static int stereo_row_reach(const StereoGeom &G)
     for (int l = 0; l < G.nlevels; ++l) mx = std::max(mx, G.sf[l]);
     return (int)ceilf(2.0f * mx) + 1;
 }
+struct StereoScales;
+static StereoScales stereo_scales(const StereoGeom &G);
 // Batched stereo: pair p uses frame l0 + p*ls of the left arrays/pyramids and r0 + p*rs of the right ones.
 struct StereoBatch {
     const int *n_l, *n_r;   // per-frame keypoint counts on the device, or null (use the nl / nr arguments)
@@ -2204,8 +2206,10 @@ struct StereoBatch {
 // the nr right keypoints.  One workgroup per pair; rowstart[nrows + 1], order[nr] (order inside a row is irrelevant: the
 // match is the minimum of (distance, index) keys).
 constexpr int kStereoRowsMax = 4096;
+struct StereoScales { float sf[ORBHIP_MAX_LEVELS]; };
 __global__ __launch_bounds__(256) void k_stereo_sort(const orbhip_keypoint *__restrict__ kr, int nr, int nrows,
-                                                     int *__restrict__ rowstart, int *__restrict__ order, StereoBatch B)
+                                                     int *__restrict__ rowstart, int4 *__restrict__ order, StereoBatch B,
+                                                     StereoScales SF)
 {
     __shared__ int s_cnt[kStereoRowsMax];
     __shared__ int s_wave[4];
@@ -2229,14 +2233,27 @@ __global__ __launch_bounds__(256) void k_stereo_sort(const orbhip_keypoint *__re
     for (int r = r0; r < r1; ++r) { const int c = s_cnt[r]; s_cnt[r] = base; rowstart[r] = base; base += c; }
     if (tid == 255) rowstart[nrows] = base;
     __syncthreads();
-    for (int i = tid; i < nr; i += 256) order[atomicAdd(&s_cnt[min(max((int)floorf(kr[i].y), 0), nrows - 1)], 1)] = i;
+    // the sorted order holds RECORDS, not indices: everything k_stereo_match needs to gate a candidate -- x, the row band
+    // [floor(y - r), ceil(y + r)] with r = 2 * scale[octave] (same float operations as Frame.cc:483-493; clamped to
+    // [0, 4095], which no comparison against an image row can tell), the octave, the index -- in one 16-byte load instead
+    // of an index load followed by a dependent 28-byte keypoint load and a 15-way select of the scale per candidate
+    for (int i = tid; i < nr; i += 256) {
+        const orbhip_keypoint k = kr[i];
+        float sfo = SF.sf[0];
+#pragma unroll
+        for (int l = 1; l < ORBHIP_MAX_LEVELS; ++l) sfo = k.octave == l ? SF.sf[l] : sfo;
+        const float r = __fmul_rn(2.0f, sfo);
+        const int minr = min(max((int)floorf(__fsub_rn(k.y, r)), 0), 4095), maxr = min(max((int)ceilf(__fadd_rn(k.y, r)), 0), 4095);
+        const int pos = atomicAdd(&s_cnt[min(max((int)floorf(k.y), 0), nrows - 1)], 1);
+        order[pos] = make_int4(__float_as_int(k.x), minr | (maxr << 12) | ((k.octave & 15) << 24), i, 0);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_stereo_match(const orbhip_keypoint *__restrict__ kl,
                                                       const uint8_t *__restrict__ dl, int nl,
                                                       const orbhip_keypoint *__restrict__ kr,
                                                       const uint8_t *__restrict__ dr, int nr,
-                                                      const int *__restrict__ rowstart, const int *__restrict__ order, int R,
+                                                      const int *__restrict__ rowstart, const int4 *__restrict__ order, int R,
                                                       StereoGeom G,
                                                       float *__restrict__ uRight, float *__restrict__ depth,
                                                       int *__restrict__ sad, StereoBatch B)
@@ -2271,75 +2288,126 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbhip_keypoint *__r
     const uint32_t *qp = reinterpret_cast<const uint32_t *>(dl + (size_t)iL * 32);
 #pragma unroll
     for (int i = 0; i < 8; ++i) qd[i] = qp[i];
+    // The kernel is a chain of dependent memory round trips (keypoint -> row range -> candidate records -> descriptors ->
+    // right patch), so what does not depend on the match leaves early: the left 11x11 patch of the sub-pixel refinement
+    // (:555-592; it needs the left keypoint alone and lies inside the padded plane for every keypoint) is requested here.
+    const float scaleFactor = G.isf[levelL];
+    const float scaleduL = roundf(__fmul_rn(kpL.x, scaleFactor));
+    const float scaledvL = roundf(__fmul_rn(kpL.y, scaleFactor));
+    const int w = 5, L = 5;
+    const uint8_t *imL = G.left[levelL] + pyr_off_l, *imR = G.right[levelL] + pyr_off_r;
+    const int stL = G.pitch_l[levelL], stR = G.pitch_r[levelL];
+    const int cu = (int)scaleduL, cv = (int)scaledvL;
+    // Both patches travel as byte-unaligned DWORD loads into a per-wavefront LDS tile -- one load instruction for the left
+    // 11 x 12-byte window, two for the right 11 x 24-byte one (11 x 21 needed: 11 columns x 11 shifts) -- and are read
+    // from there byte by byte: the 35 byte-gather loads per lane this replaces (2 + 11 x 3) kept the texture addresser,
+    // not the ALUs, busy (67 us per 64 pairs with any amount of arithmetic removed).
+    __shared__ uint32_t s_patch[4][11 * 3 + 11 * 6 + 1];
+    uint32_t *sl = s_patch[threadIdx.x >> 6], *sr = sl + 11 * 3;
+    uint32_t lw = 0;
+    if (lane < 33) {
+        const int prow = (lane * 43) >> 7, pc = lane - prow * 3;     // lane / 3 for lane < 33
+        __builtin_memcpy(&lw, imL + (ptrdiff_t)(cv - w + prow) * stL + (cu - w) + 4 * pc, 4);
+    }
+    // each lane owns up to 2 of the 121 patch pixels
+    int dyv[2], dxv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int p = lane + 64 * t;
+        dyv[t] = p / 11 - w; dxv[t] = p % 11 - w;
+    }
     // best right keypoint on this row: smallest (dist, iR) with dist < TH_HIGH (:522-549).  Candidates: the rows within R
     // of this one in the row-sorted order (all right keypoints when there is no order)
-    unsigned long long best = ((unsigned long long)TH_HIGH << 32);
+    // key = distance << 20 | index (distances <= 256, indices < 2^20: checked on the host): the wave minimum is six
+    // v_min_u32 on the DPP path instead of six 64-bit compare-select steps
+    uint32_t best = (uint32_t)TH_HIGH << 20;
+    float bestx = 0.f;               // x of this lane's best candidate (travels with the key: no keypoint reload after the minimum)
     int jb = 0, je = nr;
     if (rowstart) { jb = rowstart[max(row - R, 0)]; je = rowstart[min(row + R + 1, G.nrows)]; }
     for (int j0 = jb; j0 < je; j0 += 64) {
         const int j = j0 + lane;
         if (j < je) {
-            const int iR = rowstart ? order[j] : j;
-            const orbhip_keypoint kpR = kr[iR];
-            float sfo = G.sf[0];   // scale of the right keypoint's level, by selects (a lane-indexed read would put G into scratch)
+            int iR, minr, maxr, octR;
+            float xR;
+            if (rowstart) {
+                const int4 rc = order[j];
+                xR = __int_as_float(rc.x); minr = rc.y & 4095; maxr = (rc.y >> 12) & 4095; octR = rc.y >> 24; iR = rc.z;
+            } else {
+                iR = j;
+                const orbhip_keypoint kpR = kr[iR];
+                float sfo = G.sf[0];   // scale of the right keypoint's level, by selects (a lane-indexed read would put G into scratch)
 #pragma unroll
-            for (int l = 1; l < ORBHIP_MAX_LEVELS; ++l) sfo = kpR.octave == l ? G.sf[l] : sfo;
-            const float r = __fmul_rn(2.0f, sfo);
-            const int minr = (int)floorf(__fsub_rn(kpR.y, r)), maxr = (int)ceilf(__fadd_rn(kpR.y, r));
-            if (row >= minr && row <= maxr && !(kpR.octave < levelL - 1 || kpR.octave > levelL + 1) &&
-                kpR.x >= minU && kpR.x <= maxU) {
+                for (int l = 1; l < ORBHIP_MAX_LEVELS; ++l) sfo = kpR.octave == l ? G.sf[l] : sfo;
+                const float r = __fmul_rn(2.0f, sfo);
+                minr = (int)floorf(__fsub_rn(kpR.y, r)); maxr = (int)ceilf(__fadd_rn(kpR.y, r));
+                octR = kpR.octave; xR = kpR.x;
+            }
+            if (row >= minr && row <= maxr && !(octR < levelL - 1 || octR > levelL + 1) && xR >= minU && xR <= maxU) {
                 const uint32_t *tp = reinterpret_cast<const uint32_t *>(dr + (size_t)iR * 32);
                 uint32_t td[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) td[i] = tp[i];
-                unsigned long long key = ((unsigned long long)hamming256(qd, td) << 32) | (uint32_t)iR;
-                best = key < best ? key : best;
+                const uint32_t key = ((uint32_t)hamming256(qd, td) << 20) | (uint32_t)iR;
+                if (key < best) { best = key; bestx = xR; }
             }
         }
     }
-    best = wave_min_u64(best);
-    const int bestDist = (int)(best >> 32);
+    const uint32_t mine_key = best;
+    best = (uint32_t)wave_min((int)best);          // keys are < 2^31: the signed minimum is the unsigned one
+    const int bestDist = (int)(best >> 20);
     const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
     if (!(bestDist < thOrbDist)) return;
-    const int bestIdxR = (int)(best & 0xffffffffu);
-    // sub-pixel refinement by 11x11 SAD over 11 shifts at the keypoint's level (:555-592)
-    const float uR0 = kr[bestIdxR].x;
-    const float scaleFactor = G.isf[levelL];
-    const float scaleduL = roundf(__fmul_rn(kpL.x, scaleFactor));
-    const float scaledvL = roundf(__fmul_rn(kpL.y, scaleFactor));
+    // sub-pixel refinement by 11x11 SAD over 11 shifts at the keypoint's level (:555-592); x of the winner from the lane that holds it
+    const unsigned long long owner = __ballot(mine_key == best);
+    const float uR0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bestx), __ffsll((long long)owner) - 1));
     const float scaleduR0 = roundf(__fmul_rn(uR0, scaleFactor));
-    const int w = 5, L = 5;
     const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)L), (float)w);
     const float endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, (float)L), (float)w), 1.0f);
     if (iniu < 0 || endu >= (float)G.cols_r[levelL]) return;
-    const uint8_t *imL = G.left[levelL] + pyr_off_l, *imR = G.right[levelL] + pyr_off_r;
-    const int stL = G.pitch_l[levelL], stR = G.pitch_r[levelL];
-    const int cu = (int)scaleduL, cv = (int)scaledvL, cr = (int)scaleduR0;
-    const int cL = imL[(ptrdiff_t)cv * stL + cu];
-    // each lane owns up to 2 of the 121 patch pixels
-    int pl[2], dyv[2], dxv[2];
+    const int cr = (int)scaleduR0;
+    // stage the two windows: right window = rows cv-5 .. cv+5, bytes cr-10 .. cr+13 (columns beyond cr+10 are never read;
+    // they lie inside the padded plane: cr + 11 < cols was just checked)
+    if (lane < 33) sl[lane] = lw;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        int p = lane + 64 * t;
-        dyv[t] = p / 11 - w; dxv[t] = p % 11 - w;
-        pl[t] = p < 121 ? (int)imL[(ptrdiff_t)(cv + dyv[t]) * stL + cu + dxv[t]] - cL : 0;
+        const int idx = lane + 64 * t;
+        if (idx < 66) {
+            const int prow = (idx * 43) >> 8, pc = idx - prow * 6;     // idx / 6 for idx < 66
+            uint32_t rw;
+            __builtin_memcpy(&rw, imR + (ptrdiff_t)(cv - w + prow) * stR + (cr - 2 * w) + 4 * pc, 4);
+            sr[idx] = rw;
+        }
     }
-    int dists[11];
+    __builtin_amdgcn_wave_barrier();          // DS operations of a wavefront execute in order
+    const uint8_t *bl = reinterpret_cast<const uint8_t *>(sl), *br = reinterpret_cast<const uint8_t *>(sr);
+    const int cL = bl[5 * 12 + 5];
+    int pl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) pl[t] = lane + 64 * t < 121 ? (int)bl[(dyv[t] + w) * 12 + dxv[t] + w] - cL : 0;
+    // SAD of the 11 shifts; a shift's total is at most 121 * 510 < 2^16, so two shifts share one wave sum
+    int accs[11];
 #pragma unroll
     for (int s = 0; s < 11; ++s) {
         const int incR = s - L;
-        const int cR = imR[(ptrdiff_t)cv * stR + cr + incR];
+        const int cR = br[5 * 24 + 2 * w + incR];
         int acc = 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             int p = lane + 64 * t;
             if (p < 121) {
-                int b = (int)imR[(ptrdiff_t)(cv + dyv[t]) * stR + cr + incR + dxv[t]] - cR;
+                int b = (int)br[(dyv[t] + w) * 24 + 2 * w + incR + dxv[t]] - cR;
                 acc += abs(pl[t] - b);
             }
         }
-        dists[s] = wave_reduce_add_i(acc);
+        accs[s] = acc;
     }
+    int dists[11];
+#pragma unroll
+    for (int s = 0; s < 10; s += 2) {
+        const uint32_t two = (uint32_t)wave_reduce_add_i(accs[s] | (accs[s + 1] << 16));
+        dists[s] = (int)(two & 0xffffu); dists[s + 1] = (int)(two >> 16);
+    }
+    dists[10] = wave_reduce_add_i(accs[10]);
     int bestD = INT_MAX, bestincR = 0;
 #pragma unroll
     for (int s = 0; s < 11; ++s) if (dists[s] < bestD) { bestD = dists[s]; bestincR = s - L; }
@@ -2363,6 +2431,13 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbhip_keypoint *__r
             sad[iL] = bestD;
         }
     }
+}
+
+static StereoScales stereo_scales(const StereoGeom &G)
+{
+    StereoScales S;
+    for (int l = 0; l < ORBHIP_MAX_LEVELS; ++l) S.sf[l] = G.sf[l < G.nlevels ? l : 0];
+    return S;
 }
 
 // median-based outlier cull (:626-639): thDist = 1.5f*1.4f*median of the SAD list sorted by
@@ -2395,20 +2470,43 @@ __global__ __launch_bounds__(256) void k_stereo_cull(int nl, const int *__restri
     const bool in_lds = nl <= kResolveMax;
     if (in_lds) for (int i = tid; i < nl; i += 256) s_sad[i] = sad[i];
     __syncthreads();
-    if (tid < 64) {
-        int lo = 0, hi = 11 * 11 * 510;        // L1 norm of two 11 x 11 byte windows, each minus its centre pixel
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            int c = 0;
-            for (int i = tid; i < nl; i += 64) {
-                const int d = in_lds ? s_sad[i] : sad[i];
-                c += (d >= 0) && (d <= mid);
-            }
-            c = wave_sum(c);
-            if (c > target) hi = mid; else lo = mid + 1;
+    // The values are L1 norms of two 11 x 11 byte windows, each minus its centre pixel: <= 11 * 11 * 510 < 2^16.  Two-level
+    // radix select over all 256 threads: histogram of the high bytes, the bin that holds rank `target` (smallest v with
+    // count(d <= v) > target), then the histogram of the low bytes inside that bin -- four barriers instead of 16
+    // dependent bisection probes by one wavefront (26 -> 9 us per 64 pairs).
+    __shared__ int s_hist[256];
+    __shared__ int s_bin, s_rank;
+    int rank = target, value = 0;
+#pragma unroll 1
+    for (int level = 0; level < 2; ++level) {
+        s_hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < nl; i += 256) {
+            const int d = in_lds ? s_sad[i] : sad[i];
+            if (d < 0) continue;
+            if (level == 0) atomicAdd(&s_hist[d >> 8], 1);
+            else if ((d >> 8) == value) atomicAdd(&s_hist[d & 255], 1);
         }
-        if (tid == 0) s_med = lo;
+        __syncthreads();
+        if (tid < 64) {
+            const int h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
+            const int sum = h0 + h1 + h2 + h3, incl = wave_incl_scan_add(sum);
+            const unsigned long long over = __ballot(incl > rank);       // non-empty: the total count exceeds the rank
+            if (tid == __ffsll((long long)over) - 1) {
+                int c = incl - sum, bin = 4 * tid;                        // first bin of this lane whose running count passes the rank
+                if (c + h0 > rank) { }
+                else if (c + h0 + h1 > rank) { c += h0; bin += 1; }
+                else if (c + h0 + h1 + h2 > rank) { c += h0 + h1; bin += 2; }
+                else { c += h0 + h1 + h2; bin += 3; }
+                s_bin = bin; s_rank = rank - c;
+            }
+        }
+        __syncthreads();
+        value = level == 0 ? s_bin : (value << 8) | s_bin;
+        rank = s_rank;
+        __syncthreads();
     }
+    if (tid == 0) s_med = value;
     __syncthreads();
     const float median = (float)s_med;
     const float thDist = __fmul_rn(1.5f * 1.4f, median);
@@ -3343,6 +3441,7 @@ int orbhip_compute_stereo_matches_device(orbhip_matcher *m, orbhip_extractor *le
         set_error("stereo: extractor handles do not hold the requested frames on device %d", m->device);
         return ORBHIP_E_ARG;
     }
+    if (cap > (1 << 20)) { set_error("stereo: capacity %d exceeds the 2^20 keypoints the match key holds", cap); return ORBHIP_E_CAPACITY; }
     ORBHIP_HIP_CHECK(hipSetDevice(m->device));
     // mvImagePyramid[0] of handles that produce it on demand; this launch is ordered behind the copy
     if (int rc = ensure_level0(left, m->stream)) return rc;
@@ -3360,19 +3459,20 @@ int orbhip_compute_stereo_matches_device(orbhip_matcher *m, orbhip_extractor *le
     for (int l = G.nlevels; l < ORBHIP_MAX_LEVELS; ++l) { G.left[l] = G.left[0]; G.right[l] = G.right[0]; }
     void *p;
     int rc;
-    if ((rc = scratch(m, S_ORD, (size_t)pairs * ((size_t)G.nrows + 1 + cap) * sizeof(int), &p))) return rc;
-    int *d_rowstart = (int *)p, *d_order = d_rowstart + (size_t)pairs * (G.nrows + 1);
+    if ((rc = scratch(m, S_ORD, al256((size_t)pairs * ((size_t)G.nrows + 1) * sizeof(int)) + (size_t)pairs * cap * sizeof(int4), &p))) return rc;
+    int *d_rowstart = (int *)p;
+    int4 *d_order = reinterpret_cast<int4 *>((uint8_t *)p + al256((size_t)pairs * ((size_t)G.nrows + 1) * sizeof(int)));
     if ((rc = scratch(m, S_CNT, (size_t)pairs * cap * sizeof(int), &p))) return rc;
     int *d_sad = (int *)p;
     const StereoBatch B = {(const int *)d_n_l, (const int *)d_n_r, l0, ls, r0, rs, cap, left->G.frame_bytes, right->G.frame_bytes};
     const int R = stereo_row_reach(G);
     if (G.nrows <= kStereoRowsMax)
         hipLaunchKernelGGL(k_stereo_sort, dim3(pairs), dim3(256), 0, m->stream, (const orbhip_keypoint *)d_kps_r, cap, G.nrows, d_rowstart,
-                           d_order, B);
+                           d_order, B, stereo_scales(G));
     else d_rowstart = nullptr;   // taller images: every right keypoint is a candidate
     hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, pairs), dim3(256), 0, m->stream, (const orbhip_keypoint *)d_kps_l,
                        (const uint8_t *)d_desc_l, cap, (const orbhip_keypoint *)d_kps_r, (const uint8_t *)d_desc_r, cap,
-                       (const int *)d_rowstart, (const int *)d_order, R, G, (float *)d_u_right, (float *)d_depth, d_sad, B);
+                       (const int *)d_rowstart, (const int4 *)d_order, R, G, (float *)d_u_right, (float *)d_depth, d_sad, B);
     hipLaunchKernelGGL(k_stereo_cull, dim3(pairs), dim3(256), 0, m->stream, cap, d_sad, (float *)d_u_right, (float *)d_depth,
                        (int *)d_nmatches, B);
     ORBHIP_HIP_CHECK(hipGetLastError());
@@ -3655,6 +3755,7 @@ int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int
     for (int i = 0; i < nl; ++i) { u_right[i] = -1.0f; depth[i] = -1.0f; }
     *nmatches = 0;
     if (nl == 0 || nr == 0) return ORBHIP_OK;
+    if (nr > (1 << 20)) { set_error("stereo: %d right keypoints exceed the 2^20 the match key holds", nr); return ORBHIP_E_CAPACITY; }
     ORBHIP_HIP_CHECK(hipSetDevice(m->device));
     if (int rc = ensure_level0(left, nullptr)) return rc;     // mvImagePyramid[0] of handles that produce it on demand
     if (int rc = ensure_level0(right, nullptr)) return rc;
@@ -3681,8 +3782,9 @@ int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int
     const orbhip_keypoint *d_kr = (const orbhip_keypoint *)st.put(keys_r, (size_t)nr * sizeof(orbhip_keypoint));
     const uint8_t *d_dr = (const uint8_t *)st.put(desc_r, (size_t)nr * 32);
     if ((rc = stage_commit(m, &st))) return rc;
-    if ((rc = scratch(m, S_ORD, ((size_t)G.nrows + 1 + nr) * sizeof(int), &p))) return rc;
-    int *d_rowstart = (int *)p, *d_order = d_rowstart + (G.nrows + 1);
+    if ((rc = scratch(m, S_ORD, al256(((size_t)G.nrows + 1) * sizeof(int)) + (size_t)nr * sizeof(int4), &p))) return rc;
+    int *d_rowstart = (int *)p;
+    int4 *d_order = reinterpret_cast<int4 *>((uint8_t *)p + al256(((size_t)G.nrows + 1) * sizeof(int)));
     // outputs contiguous: u_right[nl] | depth[nl] | sad[nl] | n
     if ((rc = scratch(m, S_OUT, (size_t)(3 * nl + 1) * sizeof(float), &p))) return rc;
     float *d_ur = (float *)p, *d_depth = d_ur + nl;
@@ -3691,10 +3793,10 @@ int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int
     if ((rc = out_buffer(m, (size_t)(3 * nl + 1) * sizeof(float), &h_out))) return rc;
     const StereoBatch one = {nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
     if (G.nrows <= kStereoRowsMax)
-        hipLaunchKernelGGL(k_stereo_sort, dim3(1), dim3(256), 0, m->stream, d_kr, nr, G.nrows, d_rowstart, d_order, one);
+        hipLaunchKernelGGL(k_stereo_sort, dim3(1), dim3(256), 0, m->stream, d_kr, nr, G.nrows, d_rowstart, d_order, one, stereo_scales(G));
     else d_rowstart = nullptr;
     hipLaunchKernelGGL(k_stereo_match, dim3((nl + 3) / 4), dim3(256), 0, m->stream, d_kl, d_dl, nl, d_kr, d_dr, nr,
-                       (const int *)d_rowstart, (const int *)d_order, stereo_row_reach(G), G, d_ur, d_depth, d_sad, one);
+                       (const int *)d_rowstart, (const int4 *)d_order, stereo_row_reach(G), G, d_ur, d_depth, d_sad, one);
     hipLaunchKernelGGL(k_stereo_cull, dim3(1), dim3(256), 0, m->stream, nl, d_sad, d_ur, d_depth, d_n, one);
     ORBHIP_HIP_CHECK(hipGetLastError());
     ORBHIP_HIP_CHECK(hipMemcpyAsync(h_out, d_ur, (size_t)(3 * nl + 1) * sizeof(float), hipMemcpyDeviceToHost, m->stream));
