@@ -442,6 +442,7 @@ __global__ __launch_bounds__(256) void k_bow_groups(const NodeGroup *__restrict_
 // binary search in the sorted train keys, then the 16 wavefronts take the common nodes round-robin and replay each
 // node's queries in order exactly like k_bow_groups; rotation histogram, cull and count finish in the same launch.
 constexpr int kBowPairMax = 4096;
+constexpr int kBowStage = 64;       // queries of a node whose descriptors a wavefront fetches in one go
 struct BowPairShared {
     unsigned long long qkey[kBowPairMax], tkey[kBowPairMax];
     int mout[kBowPairMax];
@@ -449,6 +450,8 @@ struct BowPairShared {
     unsigned char matched[kBowPairMax], bin[kBowPairMax];
     int hist[HISTO_LENGTH];
     int nq, nt, ngroups, nmatch;
+    uint32_t qstage[16][kBowStage * 8];   // per wavefront: the descriptors of up to kBowStage queries of the node it replays
+    unsigned short gt0[kBowPairMax], gt1[kBowPairMax], gq1[kBowPairMax];   // per group: train range, end of the query range
 };
 struct BowSide {   // one side of the pairs, in the extractor / vocabulary output layout
     const orbhip_keypoint *kps;
@@ -509,7 +512,12 @@ __global__ __launch_bounds__(1024) void k_bow_pairs(BowSide Q, BowSide T, int ca
                     if ((c > d) == up) { S.tkey[i] = d; S.tkey[l] = c; }
                 }
             }
-            __syncthreads();
+            // A thread's elements are tid, tid + 1024, ...: a wavefront owns aligned blocks of 64 elements.  While the
+            // partner distance of this step and of the next one is below 64, every element a wavefront touches belongs to
+            // it: its DS operations execute in order and no workgroup barrier is needed (41 of the 55 steps of P = 1024).
+            const int jn = j > 1 ? (j >> 1) : k;            // partner distance of the next step
+            if (j >= 64 || jn >= 64) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();
         }
     for (int i = tid; i < P; i += NT) {   // sizes of the valid prefixes; group heads of the query side
         if (S.qkey[i] != ~0ull) {
@@ -524,12 +532,20 @@ __global__ __launch_bounds__(1024) void k_bow_pairs(BowSide Q, BowSide T, int ca
     }
     __syncthreads();
     const int nq = S.nq, nt = S.nt, ng = S.ngroups;
+    // ranges of every group by one thread each (three binary searches that the wavefront replaying the group would
+    // otherwise run one after the other, 30 dependent LDS reads per group on the serial path)
+    for (int g = tid; g < ng; g += NT) {
+        const unsigned long long nodekey = S.qkey[S.ghead[g]] & 0xffffffff00000000ull;
+        S.gt0[g] = (unsigned short)lower_bound_u64(S.tkey, nt, nodekey);
+        S.gt1[g] = (unsigned short)lower_bound_u64(S.tkey, nt, nodekey + (1ull << 32));
+        S.gq1[g] = (unsigned short)lower_bound_u64(S.qkey, nq, nodekey + (1ull << 32));
+    }
+    __syncthreads();
     for (int g = wave; g < ng; g += NT / 64) {
         const int q_begin = S.ghead[g];
-        const unsigned long long nodekey = S.qkey[q_begin] & 0xffffffff00000000ull;
-        const int t_begin = lower_bound_u64(S.tkey, nt, nodekey), t_end = lower_bound_u64(S.tkey, nt, nodekey + (1ull << 32));
+        const int t_begin = S.gt0[g], t_end = S.gt1[g];
         if (t_end <= t_begin) continue;   // node absent from the frame
-        const int q_end = lower_bound_u64(S.qkey, nq, nodekey + (1ull << 32));
+        const int q_end = S.gq1[g];
         const int tc = t_end - t_begin;
         uint32_t td0[8];
         const bool have0 = lane < tc;
@@ -539,45 +555,62 @@ __global__ __launch_bounds__(1024) void k_bow_pairs(BowSide Q, BowSide T, int ca
             for (int i = 0; i < 8; ++i) td0[i] = have0 ? tp[i] : 0u;
         }
         bool used0 = have0 ? S.matched[t_begin + lane] != 0 : true;
+        uint32_t *qs = S.qstage[wave];
         for (int qi = q_begin; qi < q_end; ++qi) {
-            const int idx1 = (int)(uint32_t)S.qkey[qi];
+            // The queries of a node are replayed one after the other (each may take a slot from the next), but their
+            // descriptors do not depend on that: the wavefront fetches them kBowStage at a time -- lanes = dwords, a few
+            // load instructions, ONE memory round trip -- into its LDS stage instead of waiting for a 32-byte load per query.
+            const int qo = (qi - q_begin) & (kBowStage - 1);
+            if (qo == 0) {
+                const int nst = min(kBowStage, q_end - qi);
+                __builtin_amdgcn_wave_barrier();          // the previous chunk's reads are done (DS operations execute in order)
+                for (int e = lane; e < nst * 8; e += 64)
+                    qs[e] = reinterpret_cast<const uint32_t *>(qd + (size_t)(uint32_t)S.qkey[qi + (e >> 3)] * 32)[e & 7];
+                __builtin_amdgcn_wave_barrier();
+            }
             uint32_t qdw[8];
-            const uint32_t *qp = reinterpret_cast<const uint32_t *>(qd + (size_t)idx1 * 32);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) qdw[i] = qp[i];
-            unsigned long long k1 = ~0ull, k2 = ~0ull;
-            if (!used0) k1 = ((unsigned long long)hamming256(qdw, td0) << 32) | (unsigned)(t_begin + lane);
+            for (int i = 0; i < 8; ++i) qdw[i] = qs[qo * 8 + i];
+            // key = distance << 12 | slot (distances <= 256, slots < kBowPairMax = 4096): a wave minimum is six v_min on the
+            // DPP path instead of six 64-bit compare-select steps, twice per query
+            constexpr int kNone = 0x7fffffff;
+            int k1 = kNone, k2 = kNone;
+            if (!used0) k1 = (hamming256(qdw, td0) << 12) | (t_begin + lane);
             for (int c = t_begin + 64 + lane; c < t_end; c += 64) {
                 if (S.matched[c]) continue;
                 const uint32_t *tp = reinterpret_cast<const uint32_t *>(td + (size_t)(uint32_t)S.tkey[c] * 32);
                 uint32_t t8[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) t8[i] = tp[i];
-                const unsigned long long k = ((unsigned long long)hamming256(qdw, t8) << 32) | (unsigned)c;
+                const int k = (hamming256(qdw, t8) << 12) | c;
                 if (k < k1) { k2 = k1; k1 = k; } else if (k < k2) k2 = k;
             }
-            const unsigned long long m1 = wave_min_u64(k1);
-            if (m1 == ~0ull) continue;
-            const unsigned long long m2 = wave_min_u64(k1 == m1 ? k2 : k1);
-            const int bestDist1 = (int)(m1 >> 32), bestDist2 = m2 == ~0ull ? 256 : (int)(m2 >> 32);
+            const int m1 = wave_min(k1);
+            if (m1 == kNone) continue;
+            const int m2 = wave_min(k1 == m1 ? k2 : k1);
+            const int bestDist1 = m1 >> 12, bestDist2 = m2 == kNone ? 256 : m2 >> 12;
             if (bestDist1 <= max_dist && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
-                const int slot = (int)(uint32_t)m1;
+                const int slot = m1 & 4095;
                 if (((slot - t_begin) & 63) == lane) {
                     S.matched[slot] = 1;
                     if (slot - t_begin < 64) used0 = true;
                 }
-                if (lane == 0) {
-                    const int idx2 = (int)(uint32_t)S.tkey[slot];
-                    S.mout[qi] = idx2;
-                    if (check_ori) {
-                        const int b = rot_bin(qk[idx1].angle, tk[idx2].angle);
-                        if (b >= 0) { atomicAdd(&S.hist[b], 1); S.bin[qi] = (unsigned char)b; }
-                    }
-                }
+                if (lane == 0) S.mout[qi] = (int)(uint32_t)S.tkey[slot];
             }
         }
     }
     __syncthreads();
+    // rotation bins of the accepted matches, all at once: the two angle loads per match used to sit in the replay loop, one
+    // dependent memory round trip per accepted query on a single lane
+    if (check_ori) {
+        for (int p = tid; p < nq; p += NT) {
+            const int idx2 = S.mout[p];
+            if (idx2 < 0) continue;
+            const int b = rot_bin(qk[(uint32_t)S.qkey[p]].angle, tk[idx2].angle);
+            if (b >= 0) { atomicAdd(&S.hist[b], 1); S.bin[p] = (unsigned char)b; }
+        }
+        __syncthreads();
+    }
     int ind1 = -1, ind2 = -1, ind3 = -1;
     if (check_ori) three_maxima(S.hist, ind1, ind2, ind3);
     int cnt = 0;
