@@ -449,7 +449,7 @@ struct BowPairShared {
     unsigned short ghead[kBowPairMax];
     unsigned char matched[kBowPairMax], bin[kBowPairMax];
     int hist[HISTO_LENGTH];
-    int nq, nt, ngroups, nmatch;
+    int nq, nt, ngroups, nmatch, next_group;
     uint32_t qstage[16][kBowStage * 8];   // per wavefront: the descriptors of up to kBowStage queries of the node it replays
     unsigned short gt0[kBowPairMax], gt1[kBowPairMax], gq1[kBowPairMax];   // per group: train range, end of the query range
 };
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_bow_pairs(BowSide Q, BowSide T, int ca
     }
     for (int i = tid; i < cap; i += NT) matches12[i] = -1;
     if (tid < HISTO_LENGTH) S.hist[tid] = 0;
-    if (tid == 0) { S.nq = 0; S.nt = 0; S.ngroups = 0; S.nmatch = 0; }
+    if (tid == 0) { S.nq = 0; S.nt = 0; S.ngroups = 0; S.nmatch = 0; S.next_group = 0; }
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -541,7 +541,12 @@ __global__ __launch_bounds__(1024) void k_bow_pairs(BowSide Q, BowSide T, int ca
         S.gq1[g] = (unsigned short)lower_bound_u64(S.qkey, nq, nodekey + (1ull << 32));
     }
     __syncthreads();
-    for (int g = wave; g < ng; g += NT / 64) {
+    // the wavefronts take the groups from a counter, not round-robin: groups differ in length
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&S.next_group, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= ng) break;
         const int q_begin = S.ghead[g];
         const int t_begin = S.gt0[g], t_end = S.gt1[g];
         if (t_end <= t_begin) continue;   // node absent from the frame
