@@ -508,7 +508,8 @@ int orbhip_matcher_sync(orbhip_matcher *m);
  * handles by their last extract call (frame indices frame_l / frame_r of those batches), i.e.
  * mpORBextractorLeft/Right->mvImagePyramid.  keys/desc: host buffers (mvKeys, mDescriptors,
  * mvKeysRight, mDescriptorsRight).  mb is passed explicitly (the reference reads it before
- * assignment, src/Frame.cc:496 vs :114).  u_right[nl], depth[nl] out (mvuRight, mvDepth). */
+ * assignment, src/Frame.cc:496 vs :114).  u_right[nl], depth[nl] out (mvuRight, mvDepth).
+ * At most 2^20 right keypoints (ORBHIP_E_CAPACITY beyond: the match key holds distance << 20 | index). */
 int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int frame_l,
                                   orbhip_extractor *right, int frame_r,
                                   const orbhip_keypoint *keys_l, const uint8_t *desc_l, int nl,
@@ -520,7 +521,7 @@ int orbhip_compute_stereo_matches(orbhip_matcher *m, orbhip_extractor *left, int
  * one (left and right may be the same handle holding an interleaved batch: l0=0, ls=2, r0=1, rs=2).  Arrays are in
  * the extractor's output layout with stride `cap`.  Outputs: d_u_right / d_depth [pairs][cap] float (entries beyond
  * the left frame's count are untouched), d_nmatches [pairs] int32.  Asynchronous on the matcher's stream; the caller
- * orders it after the extractions (same stream, or orbhip_extractor_sync). */
+ * orders it after the extractions (same stream, or orbhip_extractor_sync).  cap <= 2^20 (ORBHIP_E_CAPACITY beyond). */
 int orbhip_compute_stereo_matches_device(orbhip_matcher *m, orbhip_extractor *left, int l0, int ls,
                                          orbhip_extractor *right, int r0, int rs, int pairs, const void *d_kps_l,
                                          const void *d_desc_l, const void *d_n_l, const void *d_kps_r,
