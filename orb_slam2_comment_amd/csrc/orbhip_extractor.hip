@@ -420,6 +420,7 @@ __global__ __launch_bounds__(256) void k_pyr_rows(uint8_t *__restrict__ pyr, uin
 constexpr int kSubMax = 72;              // max (wCell+6), (hCell+6)
 constexpr int kFastStageU = 12;         // k_fast_cells: row groups per staging batch (48 rows of a stride <= 16 dwords)
 constexpr int kFastLdsPerCu = 160 * 1024;  // gfx950
+constexpr int kFastLdsGranule = 1280;      // LDS is handed out in 1280-byte granules on gfx950 (tools/micro/lds_oob.hip: a 4 KB request owns 5 KB)
 constexpr int kFastLead = 1;             // k_fast_cells: LDS column of sub-image x is x + kFastLead + 4
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
@@ -617,7 +618,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORBHIP_FAST_
     // The survivor list holds P.list_cap entries -- far fewer than the cell has pixels, so that 8 wavefronts per SIMD fit
     // the LDS.  It is the LAST array of the workgroup's LDS: entries past the end fall outside the allocation and are
     // dropped by the hardware's LDS range check (DS addresses are checked against the wavefront's LDS_SIZE: out-of-range
-    // writes are ignored; the dense-image tests and sweeps would show a neighbouring workgroup's corrupted tile otherwise.
+    // writes are ignored -- tools/micro/lds_oob.hip: 32,768 workgroups writing 8 KB behind their 4 KB, 50 rounds, no word of
+    // any workgroup changed, only the workgroup's own granule padding took the data; the dense-image tests and sweeps
+    // would show a neighbouring workgroup's corrupted tile otherwise.
     // A software check -- stop a round when fewer than 256 entries of room are left -- was measured at +4 %: it sends every
     // cell within 256 entries of the capacity to the band path).  A round whose survivor count exceeds the capacity is repeated in bands
     // of rows that cannot overflow (4 * ngrp pixels per row); banded rounds leave their corners in the score map only and
@@ -1866,7 +1869,7 @@ static int bind_geometry(orbhip_extractor *e, int rows, int cols)
             const int full = mdw * mdh, row_px = 4 * ((mdw + 3) >> 2), fixed = (F2.img_words + F2.score_words) * 4;
             int cap = full;
             for (int wgs = 32; wgs >= 4; wgs -= 4) {
-                const int share = (kFastLdsPerCu / wgs) & ~511;            // LDS is handed out in 512-byte granules
+                const int share = kFastLdsPerCu / wgs / kFastLdsGranule * kFastLdsGranule;
                 const int room = (share - fixed) / 2 - 2;
                 if (room >= std::max(128, row_px)) { cap = std::min(full, room); break; }
             }
