@@ -233,15 +233,15 @@ def main():
                     help="rehearsal: run the multi-rank code path (RCCL init, gather, all_reduce) even with one rank")
     ap.add_argument("--out-buffers", type=int, default=4,
                     help="multi-GPU: output sets per rank that rotate between the pipelines and the gather stream (>= 2)")
-    ap.add_argument("--gates", default="0",
+    ap.add_argument("--gates", default="auto",
                     help="comma-separated extractor stages (0 pyramid, 1 FAST, 2 octree, 3 descriptors) whose launches are chained "
                          "in a ring over the pipelines (orbhip_extractor_set_stage_gate): pipeline h's stage waits for pipeline "
-                         "h-1's")
+                         "h-1's.  Default \"auto\": the pyramid ring (\"0\") from 384 frames per GPU up, none below (measured on one MI355X: "
+                         "512 frames 290 k with the ring / 287 k without; 256: 273 / 276 k; 128: 245 / 261 k; 64: 220 / 227 k frames/s)")
     ap.add_argument("--handles", type=int, default=0,
                     help="pipelines per GPU; the per-GPU batch is split evenly between them and they run concurrently "
-                         "on separate HIP streams (extractor + matcher handle each).  Default: 3 from 192 frames per GPU up, "
-                         "2 below (64 frames per GPU, configs[3] on 8 GPUs: 203 k frames/s per GPU against 192 k with 3 and 187 k "
-                         "with 1; 128 frames: 244 k either way)")
+                         "on separate HIP streams (extractor + matcher handle each).  Default: 3 from 64 frames per GPU up (64 frames per GPU, "
+                         "configs[3] on 8 GPUs, without gates: 227 k frames/s per GPU against 223 k with 2 and 196 k with 1), 2 below")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -372,7 +372,7 @@ def main():
                                    "included) for every pair; monocular handles: mvImagePyramid[0] on demand "
                                    "(orbhip_extractor_set_lazy_level0), never asked for here" % (B * world, B) +
                                    ("; pairs round-robin over the GPUs + RCCL gather of the result slots to rank 0" if world > 1 else ""),
-                       "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": B // 2, "handles_per_gpu": head.Hn,
+                       "frames_per_gpu_per_step": B, "pairs_per_gpu_per_step": B // 2, "handles_per_gpu": head.Hn, "stage_gates": head.gates,
                        "frames_per_launch": head.splits, "mean_frames_per_launch": Bm, "global_batch": B * world, "nfeatures": NFEAT,
                        "levels": NLEVELS, "mean_keypoints_per_frame": res["mean_kp"],
                        "mean_matches_per_pair": res["mean_matches"],
@@ -436,7 +436,7 @@ class Headline:
         self.frames = frames = np.stack([uniq[(1 + (li // 2) % 8, li % 2)] for li in range(B)])
         self.d_img = d_img = torch.from_numpy(frames).to(dev)
 
-        want = args.handles if args.handles > 0 else (3 if B >= 192 else 2)
+        want = args.handles if args.handles > 0 else (3 if B >= 64 else 2)   # 64 / 128 frames: 3 pipelines 227 / 261 k, 2: 223 / 259 k
         self.Hn = Hn = max(1, min(want, pairs_local))
         self.psplit = psplit = [pairs_local // Hn + (1 if h < pairs_local % Hn else 0) for h in range(Hn)]   # pairs per pipeline
         self.splits = splits = [2 * p for p in psplit]
@@ -453,7 +453,9 @@ class Headline:
         exts, mts, streams = self.exts, self.mts, self.streams
         # stage gates: a ring of events per gated stage (torch creates an event's handle at its first record)
         self.gate_events = []
-        for spec in [v.strip() for v in args.gates.split(",") if v.strip() != ""] if Hn > 1 else []:
+        gates = ("0" if B >= 384 else "") if args.gates == "auto" else args.gates
+        self.gates = gates
+        for spec in [v.strip() for v in gates.split(",") if v.strip() != ""] if Hn > 1 else []:
             # "a" = stage a of pipeline h waits for stage a of pipeline h-1; "a:b" = ... for stage b of pipeline h-1
             a, b = (int(v) for v in (spec.split(":") if ":" in spec else (spec, spec)))
             evs = [torch.cuda.Event() for _ in range(Hn)]
